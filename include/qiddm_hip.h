@@ -1,0 +1,155 @@
+/*
+ * qiddm_hip.h -- C ABI of the MI355X (gfx950) statevector engine behind the
+ * QIDDM quantum layers.
+ *
+ * The reference (aaai2026/QIDDM) has no FFI for this path: its boundary is the
+ * Python call `self.qnode(inputs[, weights])` on a PennyLane QNode
+ * (reference nn/qdense.py:26-38,58 ; :237-247,279 ; :406-420,465 ; :1586-1600,1633 ;
+ * nn/qconv.py:39-47) whose arithmetic lives in the third-party simulators
+ * PennyLane 0.29.0 `default.qubit.torch` / PennyLane-Lightning 0.30.0
+ * `lightning.qubit` (reference requirements.txt:44-45).  This header is the
+ * drop-in for that simulator: every entry point below is what a QNode
+ * execution (forward, parameter-shift sweep, adjoint backward) binds to.  The
+ * Python binding (ctypes) is qiddm_amd/_capi.py; INTEGRATION.md shows the stub a
+ * reference maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in signatures; `stream` is a hipStream_t
+ *     passed as void* (NULL = the null stream).
+ *   - every pointer except `circ` is a DEVICE pointer owned by the caller, who
+ *     keeps it alive until the stream has been synchronised.  No allocation,
+ *     no synchronisation and no host<->device copies happen inside any call,
+ *     so every call is hipGraph-capturable, re-entrant and thread safe.
+ *   - return value: QIDDM_OK (0) or a negative qiddm_status; a human readable
+ *     reason is available from qiddm_last_error() (thread local).
+ *   - wire w is bit (n-1-w) of the amplitude index (wire 0 = most significant),
+ *     the order qml.probs(wires=range(n)) reports.
+ *
+ * Circuit family (covers every `_circuit` of reference nn/qdense.py and the
+ * exported QConv2d of nn/qconv.py):
+ *
+ *   for round in 0..n_rounds-1:                 chained QNode calls, nn/qdense.py:464-465, 1631-1635
+ *     state <- AmplitudeEmbedding(x + enc_offset, pad_with, normalize)   (QIDDM_ENC_AMPLITUDE)
+ *              or |0...0>
+ *     for block in 0..n_blocks-1:                data re-uploading, nn/qdense.py:424-428
+ *       QIDDM_ENC_RZ : RZ(enc_scale * x_j) on every wire j
+ *       QIDDM_ENC_RY : RY(enc_scale * x_j) on every wire j, block 0 only (qml.AngleEmbedding)
+ *       StronglyEntanglingLayers(angles[round][block] : (sel_layers, n, 3), imprimitive)
+ *     out <- probs (B, 2^n)  |  <Z_i> (B, n)
+ *     x   <- out[:, 0:n]     (input of the next round)
+ */
+#ifndef QIDDM_HIP_H
+#define QIDDM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QIDDM_ABI_VERSION 1
+#define QIDDM_MAX_QUBITS_FUSED 10 /* one wavefront owns the whole slab in registers */
+
+typedef enum qiddm_status {
+  QIDDM_OK = 0,
+  QIDDM_ERR_INVALID = -1,     /* bad argument (null pointer, size, enum)            */
+  QIDDM_ERR_UNSUPPORTED = -2, /* valid request this build cannot run (e.g. n > max)  */
+  QIDDM_ERR_LAUNCH = -3       /* HIP reported a launch failure                       */
+} qiddm_status;
+
+typedef enum qiddm_encoding {
+  QIDDM_ENC_NONE = 0,
+  QIDDM_ENC_AMPLITUDE = 1, /* qml.AmplitudeEmbedding  (nn/qdense.py:41-43, nn/qconv.py:52-54) */
+  QIDDM_ENC_RZ = 2,        /* qml.RZ(inputs[:, j], wires=j) (nn/qdense.py:253, 427, 1408)     */
+  QIDDM_ENC_RY = 3         /* qml.AngleEmbedding(rotation="Y") (nn/qdense.py:166-168)        */
+} qiddm_encoding;
+
+typedef enum qiddm_imprimitive {
+  QIDDM_IMP_CNOT = 0, /* StronglyEntanglingLayers default (nn/qdense.py:44-46)              */
+  QIDDM_IMP_CZ = 1    /* imprimitive=qml.ops.CZ (nn/qdense.py:263, 428)                      */
+} qiddm_imprimitive;
+
+typedef enum qiddm_measure {
+  QIDDM_MEAS_PROBS = 0, /* qml.probs(wires=range(n))                 (nn/qdense.py:47)       */
+  QIDDM_MEAS_EXPZ = 1   /* [qml.expval(qml.PauliZ(i)) for i in ...]  (nn/qdense.py:264)      */
+} qiddm_measure;
+
+typedef enum qiddm_dtype {
+  QIDDM_F32 = 0, /* complex64 state, float I/O  (the production path)                        */
+  QIDDM_F64 = 1  /* complex128 state, double I/O (the reference's own precision, F5)         */
+} qiddm_dtype;
+
+typedef struct qiddm_circuit {
+  int32_t n_qubits;    /* 1 .. qiddm_max_qubits()                                            */
+  int32_t encoding;    /* qiddm_encoding                                                     */
+  int32_t imprimitive; /* qiddm_imprimitive                                                  */
+  int32_t measure;     /* qiddm_measure                                                      */
+  int32_t n_rounds;    /* N >= 1                                                             */
+  int32_t n_blocks;    /* L >= 1                                                             */
+  int32_t sel_layers;  /* S >= 1  (ranges r_s = (s mod (n-1)) + 1 restart in every block)    */
+  int32_t n_features;  /* columns of `inputs` that are read: <= 2^n (amplitude), >= n (RZ/RY) */
+  int32_t dtype;       /* qiddm_dtype of inputs / outputs / gate table                       */
+  int32_t reserved;    /* must be 0                                                          */
+  double enc_scale;    /* multiplies the input angles (1.0; pi/2 in nn/qdense.py:2215)       */
+  double enc_offset;   /* added to the features before amplitude embedding (nn/qconv.py:78)  */
+  double pad_with;     /* amplitude-embedding pad constant (0.1 qdense, 0.5 qconv)           */
+} qiddm_circuit_t;
+
+/* ---- introspection ------------------------------------------------------- */
+int qiddm_abi_version(void);
+int qiddm_max_qubits(void);
+const char *qiddm_last_error(void);
+
+/* number of Rot gates = n_rounds*n_blocks*sel_layers*n_qubits (= angles / 3)            */
+int64_t qiddm_num_rot_gates(const qiddm_circuit_t *circ);
+/* gate applications per sample per forward, counted as SURVEY.md section 8a             */
+int64_t qiddm_gate_count(const qiddm_circuit_t *circ);
+/* elements (of circ->dtype) in the gate table qiddm_prepare_gates writes:
+ * num_rot_gates * 7 variants * 8 reals                                                   */
+int64_t qiddm_gate_table_elems(const qiddm_circuit_t *circ);
+/* replicas of a full parameter-shift sweep: 6*num_rot_gates (+ 2*n_blocks*n for the
+ * input angles of RZ/RY encodings)                                                       */
+int64_t qiddm_num_shift_replicas(const qiddm_circuit_t *circ, int with_inputs);
+
+/* ---- gate table ----------------------------------------------------------
+ * angles: (n_rounds, n_blocks, sel_layers, n, 3) float64, the weights tensor of
+ * StronglyEntanglingLayers AFTER any host-side map (qw_map.tanh, torch.tanh).
+ * Writes for every Rot gate the 2x2 matrix RZ(omega) RY(theta) RZ(phi) (variant 0)
+ * and its six +-pi/2 parameter shifts (variants 1..6 = phi+,phi-,theta+,theta-,
+ * omega+,omega-), evaluated in float64 and rounded once to circ->dtype.
+ * Replaces qml.StronglyEntanglingLayers' decomposition into qml.Rot
+ * [PennyLane 0.29.0 templates/layers/strongly_entangling.py].                            */
+int qiddm_prepare_gates(const qiddm_circuit_t *circ, const double *angles, void *gate_table,
+                        void *stream);
+
+/* ---- forward ----------------------------------------------------------------
+ * Replaces one (n_rounds == 1) or N chained QNode executions
+ * `self.qnode(inputs, weights)` -> default.qubit.torch / lightning.qubit
+ * (reference nn/qdense.py:58, 279, 465, 1439, 1633).
+ * inputs: (batch, in_ld) row-major, first n_features columns read (may be NULL
+ *         for QIDDM_ENC_NONE).  out: (batch, out_ld) rows of 2^n probabilities or
+ *         n expectation values.  One wavefront owns one sample's 2^n-amplitude
+ *         slab for the whole circuit (n <= 10: registers).                                */
+int qiddm_forward(const qiddm_circuit_t *circ, const void *inputs, int64_t batch, int64_t in_ld,
+                  const void *gate_table, void *out, int64_t out_ld, void *stream);
+
+/* ---- parameter-shift sweep ---------------------------------------------------
+ * Replaces PennyLane's diff_method="parameter-shift" executions configured at
+ * reference nn/qdense.py:246, 1400, 1596: re-invokes the forward kernel for
+ * replicas [first_replica, first_replica + n_replicas) of the shift schedule and
+ * contracts each replica's output with the upstream gradient on the fly:
+ *     dots[r - first_replica][b] = sum_k grad_out[b][k] * out_r[b][k]
+ * Replica ids: 6*g + v (v = 0..5 -> phi+,phi-,theta+,theta-,omega+,omega-) for Rot
+ * gate g, then 6*G_rot + 2*(block*n + wire) + (0:+, 1:-) for the input angle of
+ * `wire` re-uploaded in `block`.  d/dtheta = (dots[+] - dots[-]) / 2 summed over
+ * the batch (weights) or per sample (inputs; times enc_scale).  n_rounds must be 1.      */
+int qiddm_forward_shifted(const qiddm_circuit_t *circ, const void *inputs, int64_t batch,
+                          int64_t in_ld, const void *gate_table, const void *grad_out,
+                          int64_t g_ld, int64_t first_replica, int64_t n_replicas, void *dots,
+                          void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QIDDM_HIP_H */

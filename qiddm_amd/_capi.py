@@ -1,0 +1,125 @@
+"""ctypes binding of the C ABI declared in ``include/qiddm_hip.h``.
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (or
+``python -m qiddm_amd.build``) into ``qiddm_amd/lib/libqiddm_hip.so``.  There is
+no CPU fallback: if the library is missing, ``lib()`` raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+# torch must come first: it ships its own HIP runtime (torch/lib/libamdhip64.so, soname
+# libamdhip64.so.7).  Loading ours before torch's would bind the process to /opt/rocm's copy
+# and the two runtimes then disagree about the device ("no ROCm-capable device").
+import torch  # noqa: F401
+
+LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libqiddm_hip.so")
+
+QIDDM_OK = 0
+ENC_NONE, ENC_AMPLITUDE, ENC_RZ, ENC_RY = 0, 1, 2, 3
+IMP_CNOT, IMP_CZ = 0, 1
+MEAS_PROBS, MEAS_EXPZ = 0, 1
+F32, F64 = 0, 1
+
+# every symbol include/qiddm_hip.h declares (checked by tests/test_capi_symbols.py)
+EXPORTS = (
+    "qiddm_abi_version",
+    "qiddm_max_qubits",
+    "qiddm_last_error",
+    "qiddm_num_rot_gates",
+    "qiddm_gate_count",
+    "qiddm_gate_table_elems",
+    "qiddm_num_shift_replicas",
+    "qiddm_prepare_gates",
+    "qiddm_forward",
+    "qiddm_forward_shifted",
+)
+
+
+class CircuitStruct(ctypes.Structure):
+    """``qiddm_circuit_t``."""
+
+    _fields_ = [
+        ("n_qubits", ctypes.c_int32),
+        ("encoding", ctypes.c_int32),
+        ("imprimitive", ctypes.c_int32),
+        ("measure", ctypes.c_int32),
+        ("n_rounds", ctypes.c_int32),
+        ("n_blocks", ctypes.c_int32),
+        ("sel_layers", ctypes.c_int32),
+        ("n_features", ctypes.c_int32),
+        ("dtype", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
+        ("enc_scale", ctypes.c_double),
+        ("enc_offset", ctypes.c_double),
+        ("pad_with", ctypes.c_double),
+    ]
+
+
+class QiddmError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libqiddm_hip: {msg} (status {code})")
+        self.code = code
+
+
+_lock = threading.Lock()
+_lib = None
+
+
+def _declare(lib):
+    P = ctypes.POINTER(CircuitStruct)
+    vp, i64 = ctypes.c_void_p, ctypes.c_int64
+    lib.qiddm_abi_version.restype = ctypes.c_int
+    lib.qiddm_abi_version.argtypes = []
+    lib.qiddm_max_qubits.restype = ctypes.c_int
+    lib.qiddm_max_qubits.argtypes = []
+    lib.qiddm_last_error.restype = ctypes.c_char_p
+    lib.qiddm_last_error.argtypes = []
+    for name in ("qiddm_num_rot_gates", "qiddm_gate_count", "qiddm_gate_table_elems"):
+        getattr(lib, name).restype = i64
+        getattr(lib, name).argtypes = [P]
+    lib.qiddm_num_shift_replicas.restype = i64
+    lib.qiddm_num_shift_replicas.argtypes = [P, ctypes.c_int]
+    lib.qiddm_prepare_gates.restype = ctypes.c_int
+    lib.qiddm_prepare_gates.argtypes = [P, vp, vp, vp]
+    lib.qiddm_forward.restype = ctypes.c_int
+    lib.qiddm_forward.argtypes = [P, vp, i64, i64, vp, vp, i64, vp]
+    lib.qiddm_forward_shifted.restype = ctypes.c_int
+    lib.qiddm_forward_shifted.argtypes = [P, vp, i64, i64, vp, vp, i64, i64, i64, vp, vp]
+
+
+def _preload_torch_hip_runtime():
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
+def lib():
+    """Load (once) and return the C-ABI library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"{LIB_PATH} is missing: the HIP extension has not been built. "
+                    "Run `python -c 'import __graft_entry__ as g; g.build()'` (or "
+                    "`python -m qiddm_amd.build`) from the repo root. "
+                    "qiddm_amd has no CPU fallback for the quantum layers."
+                )
+            _preload_torch_hip_runtime()
+            handle = ctypes.CDLL(LIB_PATH)
+            _declare(handle)
+            if handle.qiddm_abi_version() != 1:
+                raise RuntimeError("libqiddm_hip.so ABI version mismatch; rebuild it")
+            _lib = handle
+    return _lib
+
+
+def check(status: int):
+    if status != QIDDM_OK:
+        raise QiddmError(status, lib().qiddm_last_error().decode("utf-8", "replace"))

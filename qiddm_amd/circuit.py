@@ -1,0 +1,270 @@
+"""Circuit descriptor + torch-level execution on the HIP statevector engine.
+
+This is the layer directly above the C ABI: tensors in, tensors out, autograd
+wired to the parameter-shift sweep.  It is what a QNode call resolves to
+(``qiddm_amd/qml.py``) exactly where the reference calls PennyLane
+(``self.qnode(inputs, weights)``, reference nn/qdense.py:58, 279, 465, 1633).
+
+No CPU path: tensors must live on a HIP device and the in-tree extension must
+be built, otherwise the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass, replace
+
+import torch
+
+from . import _capi
+
+_ENC = {"none": _capi.ENC_NONE, "amplitude": _capi.ENC_AMPLITUDE, "rz": _capi.ENC_RZ, "ry": _capi.ENC_RY}
+_IMP = {"CNOT": _capi.IMP_CNOT, "CZ": _capi.IMP_CZ}
+_MEAS = {"probs": _capi.MEAS_PROBS, "expz": _capi.MEAS_EXPZ}
+_DT = {"f32": (_capi.F32, torch.float32), "f64": (_capi.F64, torch.float64)}
+
+_default_precision = "f32"
+
+
+def set_default_precision(p: str) -> None:
+    """"f32" (complex64 state; production) or "f64" (complex128; the reference's precision)."""
+    global _default_precision
+    if p not in _DT:
+        raise ValueError(f"precision must be 'f32' or 'f64', got {p!r}")
+    _default_precision = p
+
+
+def get_default_precision() -> str:
+    return _default_precision
+
+
+@dataclass(frozen=True)
+class Circuit:
+    """Host mirror of ``qiddm_circuit_t`` (see include/qiddm_hip.h for the family)."""
+
+    n_qubits: int
+    encoding: str = "rz"       # "none" | "amplitude" | "rz" | "ry"
+    imprimitive: str = "CZ"    # "CNOT" | "CZ"
+    measure: str = "expz"      # "probs" | "expz"
+    n_rounds: int = 1
+    n_blocks: int = 1
+    sel_layers: int = 1
+    n_features: int = 0        # 0 -> n_qubits for angle encodings
+    enc_scale: float = 1.0
+    enc_offset: float = 0.0
+    pad_with: float = 0.0
+
+    def __post_init__(self):
+        for name, table in (("encoding", _ENC), ("imprimitive", _IMP), ("measure", _MEAS)):
+            if getattr(self, name) not in table:
+                raise ValueError(f"{name}={getattr(self, name)!r} not in {sorted(table)}")
+
+    @property
+    def dim(self) -> int:
+        return 1 << self.n_qubits
+
+    @property
+    def out_cols(self) -> int:
+        return self.dim if self.measure == "probs" else self.n_qubits
+
+    @property
+    def angles_shape(self):
+        return (self.n_rounds, self.n_blocks, self.sel_layers, self.n_qubits, 3)
+
+    @property
+    def features(self) -> int:
+        if self.encoding in ("rz", "ry"):
+            return self.n_features or self.n_qubits
+        return self.n_features
+
+    def c_struct(self, precision: str) -> _capi.CircuitStruct:
+        return _capi.CircuitStruct(
+            n_qubits=self.n_qubits, encoding=_ENC[self.encoding], imprimitive=_IMP[self.imprimitive],
+            measure=_MEAS[self.measure], n_rounds=self.n_rounds, n_blocks=self.n_blocks,
+            sel_layers=self.sel_layers, n_features=self.features, dtype=_DT[precision][0], reserved=0,
+            enc_scale=float(self.enc_scale), enc_offset=float(self.enc_offset),
+            pad_with=float(self.pad_with))
+
+    def gate_count(self) -> int:
+        """Gate applications per sample per forward (SURVEY.md section 8a counting)."""
+        n = self.n_qubits
+        per_block = self.sel_layers * (n + (n if n > 1 else 0))
+        if self.encoding == "rz":
+            per_block += n
+        g = self.n_rounds * self.n_blocks * per_block
+        if self.encoding == "ry":
+            g += self.n_rounds * n
+        if self.encoding == "amplitude":
+            g += self.n_rounds
+        return g
+
+    def algorithmic_bytes_per_sample(self, precision: str = "f32") -> float:
+        """(G + 1/2) * 2 * 2^n * sizeof(complex)."""
+        csize = 8 if precision == "f32" else 16
+        return (self.gate_count() + 0.5) * 2 * self.dim * csize
+
+
+def _stream_ptr(device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require_device(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"qiddm_amd: {what} lives on {t.device}; the quantum layers run only on a HIP device "
+            "(MI355X). There is no CPU fallback -- move the module and its inputs to 'cuda'.")
+
+
+def _prep_inputs(circ: Circuit, inputs, dtype, device):
+    if circ.encoding == "none":
+        return None, 0, None
+    if inputs is None:
+        raise ValueError(f"encoding {circ.encoding!r} needs inputs")
+    x = inputs
+    if x.dim() == 1:
+        x = x.unsqueeze(0)
+    if x.dim() != 2:
+        raise ValueError(f"inputs must be (batch, features); got {tuple(inputs.shape)}")
+    if circ.encoding == "amplitude":
+        if x.shape[1] > circ.dim:
+            # same message PennyLane raises from AmplitudeEmbedding
+            raise ValueError(f"Features must be of length {circ.dim} or smaller; got length {x.shape[1]}.")
+        if circ.features != x.shape[1]:
+            circ = replace(circ, n_features=x.shape[1])
+    elif x.shape[1] < circ.n_qubits:
+        raise ValueError(f"angle encoding on {circ.n_qubits} wires needs >= {circ.n_qubits} "
+                         f"feature columns; got {x.shape[1]}")
+    x = x.to(device=device, dtype=dtype).contiguous()
+    return x, x.shape[1], circ
+
+
+def prepare_gates(circ: Circuit, angles: torch.Tensor, precision: str) -> torch.Tensor:
+    """angles (N,L,S,n,3) -> gate table (G,7,8) of the compute dtype, on device."""
+    _require_device(angles, "the circuit weights")
+    if tuple(angles.shape) != circ.angles_shape:
+        raise ValueError(f"angles must have shape {circ.angles_shape}; got {tuple(angles.shape)}")
+    lib = _capi.lib()
+    cs = circ.c_struct(precision)
+    a64 = angles.detach().to(torch.float64).contiguous()
+    n_elems = lib.qiddm_gate_table_elems(ctypes.byref(cs))
+    if n_elems < 0:
+        _capi.check(-1)
+    table = torch.empty(n_elems, dtype=_DT[precision][1], device=angles.device)
+    _capi.check(lib.qiddm_prepare_gates(ctypes.byref(cs), a64.data_ptr(), table.data_ptr(),
+                                        _stream_ptr(angles.device)))
+    return table
+
+
+def run_forward(circ: Circuit, inputs, angles: torch.Tensor, precision: str | None = None,
+                table: torch.Tensor | None = None) -> torch.Tensor:
+    """Raw forward (no autograd).  Returns (B, 2^n) probabilities or (B, n) <Z>."""
+    precision = precision or _default_precision
+    dtype = _DT[precision][1]
+    _require_device(angles, "the circuit weights")
+    device = angles.device
+    x, ld, circ2 = _prep_inputs(circ, inputs, dtype, device)
+    circ = circ2 or circ
+    if x is None:
+        raise ValueError("run_forward needs inputs to know the batch size; use encoding != 'none'")
+    batch = x.shape[0]
+    lib = _capi.lib()
+    if table is None:
+        table = prepare_gates(circ, angles, precision)
+    out = torch.empty(batch, circ.out_cols, dtype=dtype, device=device)
+    cs = circ.c_struct(precision)
+    _capi.check(lib.qiddm_forward(ctypes.byref(cs), x.data_ptr(), batch, ld, table.data_ptr(),
+                                  out.data_ptr(), circ.out_cols, _stream_ptr(device)))
+    return out
+
+
+def run_shift_sweep(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch.Tensor,
+                    precision: str | None = None, with_inputs: bool = True,
+                    max_dots_elems: int = 1 << 26):
+    """Full parameter-shift sweep.  Returns (grad_angles (angles_shape, f64),
+    grad_inputs (B, n) f64 or None).  One QNode round only."""
+    precision = precision or _default_precision
+    dtype = _DT[precision][1]
+    device = angles.device
+    x, ld, circ2 = _prep_inputs(circ, inputs, dtype, device)
+    circ = circ2 or circ
+    batch = x.shape[0]
+    lib = _capi.lib()
+    cs = circ.c_struct(precision)
+    table = prepare_gates(circ, angles, precision)
+    g = grad_out.to(device=device, dtype=dtype).contiguous()
+    want_inputs = with_inputs and circ.encoding in ("rz", "ry")
+    total = lib.qiddm_num_shift_replicas(ctypes.byref(cs), 1 if want_inputs else 0)
+    n_rot = lib.qiddm_num_rot_gates(ctypes.byref(cs))
+    chunk = max(2, min(65534, (max_dots_elems // max(batch, 1)) // 2 * 2, total))
+    w_sum = torch.empty(6 * n_rot, dtype=torch.float64, device=device)
+    in_dots = []
+    first = 0
+    while first < total:
+        cnt = min(chunk, total - first)
+        dots = torch.empty(cnt, batch, dtype=dtype, device=device)
+        _capi.check(lib.qiddm_forward_shifted(ctypes.byref(cs), x.data_ptr(), batch, ld,
+                                              table.data_ptr(), g.data_ptr(), g.shape[1], first, cnt,
+                                              dots.data_ptr(), _stream_ptr(device)))
+        w_hi = min(first + cnt, 6 * n_rot)
+        if first < w_hi:
+            w_sum[first:w_hi] = dots[: w_hi - first].to(torch.float64).sum(dim=1)
+        if first + cnt > 6 * n_rot:
+            in_dots.append(dots[max(0, 6 * n_rot - first):].to(torch.float64))
+        first += cnt
+    pm = w_sum.view(n_rot, 3, 2)
+    grad_angles = (0.5 * (pm[..., 0] - pm[..., 1])).view(circ.angles_shape)
+    grad_inputs = None
+    if want_inputs:
+        d = torch.cat(in_dots, dim=0).view(circ.n_blocks, circ.n_qubits, 2, batch)
+        grad_inputs = (0.5 * circ.enc_scale) * (d[:, :, 0] - d[:, :, 1]).sum(dim=0).transpose(0, 1)
+    return grad_angles, grad_inputs
+
+
+class _QNodeFunction(torch.autograd.Function):
+    """One QNode round, differentiable by parameter shift (2 evaluations per
+    gate angle, coefficient 1/2 -- the rule PennyLane applies for
+    diff_method="parameter-shift", configured at reference nn/qdense.py:246)."""
+
+    @staticmethod
+    def forward(ctx, inputs, angles, circ, precision):
+        out = run_forward(circ, inputs, angles, precision)
+        ctx.circ, ctx.precision = circ, precision
+        ctx.save_for_backward(inputs if inputs is not None else torch.empty(0), angles)
+        ctx.in_shape = None if inputs is None else tuple(inputs.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        inputs, angles = ctx.saved_tensors
+        circ = ctx.circ
+        need_in = ctx.needs_input_grad[0]
+        if need_in and circ.encoding == "amplitude":
+            raise NotImplementedError(
+                "gradient w.r.t. amplitude-embedded features is not a gate parameter; "
+                "parameter-shift cannot provide it")
+        ga, gi = run_shift_sweep(circ, inputs, angles, grad_out, ctx.precision, with_inputs=need_in)
+        grad_inputs = None
+        if need_in and gi is not None:
+            full = torch.zeros(inputs.shape if inputs.dim() == 2 else (1,) + tuple(inputs.shape),
+                               dtype=inputs.dtype, device=inputs.device)
+            full[:, : circ.n_qubits] = gi.to(inputs.dtype)
+            grad_inputs = full.view(ctx.in_shape)
+        return grad_inputs, ga.to(angles.dtype), None, None
+
+
+def execute(circ: Circuit, inputs, angles: torch.Tensor, precision: str | None = None) -> torch.Tensor:
+    """Differentiable execution of ``circ`` (all rounds).  With grad enabled the
+    rounds run one QNode call at a time, as the reference chains them
+    (nn/qdense.py:464-465); under ``torch.no_grad()`` they are fused in one launch."""
+    precision = precision or _default_precision
+    _require_device(angles, "the circuit weights")
+    needs_grad = torch.is_grad_enabled() and (
+        angles.requires_grad or (inputs is not None and inputs.requires_grad))
+    if not needs_grad:
+        return run_forward(circ, inputs, angles, precision)
+    x = inputs
+    out = None
+    one = replace(circ, n_rounds=1)
+    for r in range(circ.n_rounds):
+        out = _QNodeFunction.apply(x, angles[r:r + 1], one, precision)
+        x = out
+    return out

@@ -1,0 +1,247 @@
+// qiddm_capi.hip -- extern "C" entry points declared in include/qiddm_hip.h.
+// Argument validation, launch geometry and template dispatch only; the device
+// code lives in qsim_fused.h.
+#include "../../include/qiddm_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "qsim_fused.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int check_circuit(const qiddm_circuit_t* c) {
+  if (!c) return fail(QIDDM_ERR_INVALID, "circ is NULL");
+  if (c->n_qubits < 1) return fail(QIDDM_ERR_INVALID, "n_qubits=%d must be >= 1", c->n_qubits);
+  if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED)
+    return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d exceeds the fused-kernel limit %d", c->n_qubits,
+                QIDDM_MAX_QUBITS_FUSED);
+  if (c->encoding < QIDDM_ENC_NONE || c->encoding > QIDDM_ENC_RY)
+    return fail(QIDDM_ERR_INVALID, "unknown encoding %d", c->encoding);
+  if (c->imprimitive != QIDDM_IMP_CNOT && c->imprimitive != QIDDM_IMP_CZ)
+    return fail(QIDDM_ERR_INVALID, "unknown imprimitive %d", c->imprimitive);
+  if (c->measure != QIDDM_MEAS_PROBS && c->measure != QIDDM_MEAS_EXPZ)
+    return fail(QIDDM_ERR_INVALID, "unknown measure %d", c->measure);
+  if (c->dtype != QIDDM_F32 && c->dtype != QIDDM_F64)
+    return fail(QIDDM_ERR_INVALID, "unknown dtype %d", c->dtype);
+  if (c->n_rounds < 1 || c->n_blocks < 1 || c->sel_layers < 1)
+    return fail(QIDDM_ERR_INVALID, "n_rounds/n_blocks/sel_layers must be >= 1 (got %d/%d/%d)",
+                c->n_rounds, c->n_blocks, c->sel_layers);
+  if (c->reserved != 0) return fail(QIDDM_ERR_INVALID, "reserved field must be 0");
+  const int64_t d = (int64_t)1 << c->n_qubits;
+  if (c->encoding == QIDDM_ENC_AMPLITUDE) {
+    // PennyLane: "Features must be of length 2^n or smaller"
+    if (c->n_features < 1 || c->n_features > d)
+      return fail(QIDDM_ERR_INVALID, "Features must be of length %lld or smaller; got length %d.",
+                  (long long)d, c->n_features);
+    if (c->n_rounds != 1)
+      return fail(QIDDM_ERR_UNSUPPORTED, "amplitude encoding supports n_rounds == 1 only");
+  } else if (c->encoding == QIDDM_ENC_RZ || c->encoding == QIDDM_ENC_RY) {
+    if (c->n_features < c->n_qubits)
+      return fail(QIDDM_ERR_INVALID, "angle encoding needs n_features >= n_qubits (%d < %d)",
+                  c->n_features, c->n_qubits);
+    if (c->encoding == QIDDM_ENC_RY && c->n_blocks != 1)
+      return fail(QIDDM_ERR_UNSUPPORTED, "RY (AngleEmbedding) encoding supports n_blocks == 1 only");
+  }
+  if ((int64_t)c->n_rounds * c->n_blocks * c->sel_layers * c->n_qubits > (1 << 24))
+    return fail(QIDDM_ERR_UNSUPPORTED, "too many Rot gates");
+  return QIDDM_OK;
+}
+
+template <typename T, int N, bool SHIFT>
+int launch(const qiddm::KParams& p, int64_t n_replicas, hipStream_t stream) {
+  using L = qiddm::Layout<N>;
+  using S = qiddm::Smem<T, N>;
+  const int64_t groups = (p.batch + L::SPW - 1) / L::SPW;
+  if (groups == 0 || (SHIFT && n_replicas == 0)) return QIDDM_OK;
+  int64_t bx = (groups + qiddm::kWavesPerBlock - 1) / qiddm::kWavesPerBlock;
+  // enough blocks to fill 256 CUs several times over, then grid-stride
+  const int64_t cap = SHIFT ? 1024 : 4096;
+  if (bx > cap) bx = cap;
+  dim3 grid((unsigned)bx, SHIFT ? (unsigned)n_replicas : 1u, 1u);
+  const size_t smem = S::bytes(p.imprimitive == QIDDM_IMP_CNOT);
+  hipLaunchKernelGGL((qiddm::circuit_kernel<T, N, SHIFT>), grid, dim3(qiddm::kBlock), smem, stream, p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return fail(QIDDM_ERR_LAUNCH, "circuit_kernel<n=%d> launch failed: %s", N, hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
+template <typename T, bool SHIFT>
+int dispatch_n(int n, const qiddm::KParams& p, int64_t n_replicas, hipStream_t stream) {
+  switch (n) {
+    case 1: return launch<T, 1, SHIFT>(p, n_replicas, stream);
+    case 2: return launch<T, 2, SHIFT>(p, n_replicas, stream);
+    case 3: return launch<T, 3, SHIFT>(p, n_replicas, stream);
+    case 4: return launch<T, 4, SHIFT>(p, n_replicas, stream);
+    case 5: return launch<T, 5, SHIFT>(p, n_replicas, stream);
+    case 6: return launch<T, 6, SHIFT>(p, n_replicas, stream);
+    case 7: return launch<T, 7, SHIFT>(p, n_replicas, stream);
+    case 8: return launch<T, 8, SHIFT>(p, n_replicas, stream);
+    case 9: return launch<T, 9, SHIFT>(p, n_replicas, stream);
+    case 10: return launch<T, 10, SHIFT>(p, n_replicas, stream);
+    default: return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d not instantiated", n);
+  }
+}
+
+qiddm::KParams make_params(const qiddm_circuit_t* c) {
+  qiddm::KParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.encoding = c->encoding;
+  p.imprimitive = c->imprimitive;
+  p.measure = c->measure;
+  p.n_rounds = c->n_rounds;
+  p.n_blocks = c->n_blocks;
+  p.sel_layers = c->sel_layers;
+  p.n_features = c->n_features;
+  p.enc_scale = c->enc_scale;
+  p.enc_offset = c->enc_offset;
+  p.pad_with = c->pad_with;
+  return p;
+}
+
+int64_t out_cols(const qiddm_circuit_t* c) {
+  return c->measure == QIDDM_MEAS_PROBS ? ((int64_t)1 << c->n_qubits) : c->n_qubits;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qiddm_abi_version(void) { return QIDDM_ABI_VERSION; }
+int qiddm_max_qubits(void) { return QIDDM_MAX_QUBITS_FUSED; }
+const char* qiddm_last_error(void) { return g_err; }
+
+int64_t qiddm_num_rot_gates(const qiddm_circuit_t* c) {
+  if (check_circuit(c) != QIDDM_OK) return -1;
+  return (int64_t)c->n_rounds * c->n_blocks * c->sel_layers * c->n_qubits;
+}
+
+int64_t qiddm_gate_count(const qiddm_circuit_t* c) {
+  if (check_circuit(c) != QIDDM_OK) return -1;
+  const int64_t n = c->n_qubits;
+  int64_t per_block = (int64_t)c->sel_layers * (n + (n > 1 ? n : 0));
+  if (c->encoding == QIDDM_ENC_RZ) per_block += n;
+  int64_t g = (int64_t)c->n_rounds * c->n_blocks * per_block;
+  if (c->encoding == QIDDM_ENC_RY) g += (int64_t)c->n_rounds * n;
+  if (c->encoding == QIDDM_ENC_AMPLITUDE) g += c->n_rounds;
+  return g;
+}
+
+int64_t qiddm_gate_table_elems(const qiddm_circuit_t* c) {
+  const int64_t g = qiddm_num_rot_gates(c);
+  return g < 0 ? g : g * qiddm::kVariants * qiddm::kGateReals;
+}
+
+int64_t qiddm_num_shift_replicas(const qiddm_circuit_t* c, int with_inputs) {
+  const int64_t g = qiddm_num_rot_gates(c);
+  if (g < 0) return g;
+  int64_t r = 6 * g;
+  if (with_inputs && (c->encoding == QIDDM_ENC_RZ || c->encoding == QIDDM_ENC_RY))
+    r += 2 * (int64_t)c->n_blocks * c->n_qubits;
+  return r;
+}
+
+int qiddm_prepare_gates(const qiddm_circuit_t* c, const double* angles, void* gate_table,
+                        void* stream) {
+  int rc = check_circuit(c);
+  if (rc != QIDDM_OK) return rc;
+  if (!angles || !gate_table) return fail(QIDDM_ERR_INVALID, "angles/gate_table is NULL");
+  const int64_t n_rot = (int64_t)c->n_rounds * c->n_blocks * c->sel_layers * c->n_qubits;
+  const int64_t total = n_rot * qiddm::kVariants;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (c->dtype == QIDDM_F32)
+    hipLaunchKernelGGL(qiddm::prepare_gates_kernel<float>, dim3(blocks), dim3(256), 0, st, angles,
+                       static_cast<float*>(gate_table), n_rot);
+  else
+    hipLaunchKernelGGL(qiddm::prepare_gates_kernel<double>, dim3(blocks), dim3(256), 0, st, angles,
+                       static_cast<double*>(gate_table), n_rot);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return fail(QIDDM_ERR_LAUNCH, "prepare_gates launch failed: %s", hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
+int qiddm_forward(const qiddm_circuit_t* c, const void* inputs, int64_t batch, int64_t in_ld,
+                  const void* gate_table, void* out, int64_t out_ld, void* stream) {
+  int rc = check_circuit(c);
+  if (rc != QIDDM_OK) return rc;
+  if (batch < 0) return fail(QIDDM_ERR_INVALID, "batch=%lld < 0", (long long)batch);
+  if (batch == 0) return QIDDM_OK;
+  if (!gate_table || !out) return fail(QIDDM_ERR_INVALID, "gate_table/out is NULL");
+  if (c->encoding != QIDDM_ENC_NONE) {
+    if (!inputs) return fail(QIDDM_ERR_INVALID, "inputs is NULL but the encoding reads them");
+    if (in_ld < c->n_features)
+      return fail(QIDDM_ERR_INVALID, "in_ld=%lld < n_features=%d", (long long)in_ld, c->n_features);
+  }
+  if (out_ld < out_cols(c))
+    return fail(QIDDM_ERR_INVALID, "out_ld=%lld < %lld output columns", (long long)out_ld,
+                (long long)out_cols(c));
+  qiddm::KParams p = make_params(c);
+  p.inputs = inputs;
+  p.table = gate_table;
+  p.out = out;
+  p.in_ld = in_ld;
+  p.out_ld = out_ld;
+  p.batch = batch;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return c->dtype == QIDDM_F32 ? dispatch_n<float, false>(c->n_qubits, p, 0, st)
+                               : dispatch_n<double, false>(c->n_qubits, p, 0, st);
+}
+
+int qiddm_forward_shifted(const qiddm_circuit_t* c, const void* inputs, int64_t batch, int64_t in_ld,
+                          const void* gate_table, const void* grad_out, int64_t g_ld,
+                          int64_t first_replica, int64_t n_replicas, void* dots, void* stream) {
+  int rc = check_circuit(c);
+  if (rc != QIDDM_OK) return rc;
+  if (c->n_rounds != 1)
+    return fail(QIDDM_ERR_UNSUPPORTED,
+                "parameter-shift sweeps run one QNode round at a time (n_rounds=%d)", c->n_rounds);
+  if (batch < 0 || n_replicas < 0 || first_replica < 0)
+    return fail(QIDDM_ERR_INVALID, "negative batch/replica range");
+  const int64_t total = qiddm_num_shift_replicas(c, 1);
+  if (first_replica + n_replicas > total)
+    return fail(QIDDM_ERR_INVALID, "replicas [%lld, %lld) exceed the schedule of %lld",
+                (long long)first_replica, (long long)(first_replica + n_replicas), (long long)total);
+  if (n_replicas > 65535)
+    return fail(QIDDM_ERR_INVALID, "at most 65535 replicas per call (got %lld)", (long long)n_replicas);
+  if (batch == 0 || n_replicas == 0) return QIDDM_OK;
+  if (!gate_table || !grad_out || !dots)
+    return fail(QIDDM_ERR_INVALID, "gate_table/grad_out/dots is NULL");
+  if (c->encoding != QIDDM_ENC_NONE) {
+    if (!inputs) return fail(QIDDM_ERR_INVALID, "inputs is NULL but the encoding reads them");
+    if (in_ld < c->n_features)
+      return fail(QIDDM_ERR_INVALID, "in_ld=%lld < n_features=%d", (long long)in_ld, c->n_features);
+  }
+  if (g_ld < out_cols(c))
+    return fail(QIDDM_ERR_INVALID, "g_ld=%lld < %lld output columns", (long long)g_ld,
+                (long long)out_cols(c));
+  qiddm::KParams p = make_params(c);
+  p.inputs = inputs;
+  p.table = gate_table;
+  p.gout = grad_out;
+  p.dots = dots;
+  p.in_ld = in_ld;
+  p.g_ld = g_ld;
+  p.batch = batch;
+  p.first_replica = (int32_t)first_replica;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return c->dtype == QIDDM_F32 ? dispatch_n<float, true>(c->n_qubits, p, n_replicas, st)
+                               : dispatch_n<double, true>(c->n_qubits, p, n_replicas, st);
+}
+
+}  // extern "C"
