@@ -1,0 +1,250 @@
+#!/usr/bin/env python
+"""bench.py -- denoise-step throughput of the QIDDM quantum-layer hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): "denoise-step images/sec + gate-apps/sec, 8-qubit MNIST-28".
+Workload at every N (weak scaling, one process per GPU, no data-path collective --
+samples are independent): BASELINE configs[1] = MNIST 28x28, 8-qubit
+qdense ``QNN_noise(784, 8, 14)`` (reference default model, src/mnist_exm.py:48), batch 256 per
+GPU.  One step = one body of ``Diffusion.sample`` (reference src/models.py:127-134):
+``x <- net(x)`` on a resident (256, 1, 28, 28) float64 batch, i.e.
+linear_down -> [RZ encoders + 14 x (8 Rot + 8 CZ) + <Z>] -> linear_up.  Synthetic
+random-noise images (``rand*0.75+0.5``, src/mnist_exm.py:396), random-init weights under
+``torch.manual_seed(42)``.  The step is captured once into a hipGraph and replayed.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+BATCH_PER_GPU = 256
+N_QUBITS, QDEPTH, IMG = 8, 14, 28
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="images per GPU per step")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
+    return ap.parse_args()
+
+
+def init_dist(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+    if world != args.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
+    return world, rank, local
+
+
+def build_model(dev):
+    from qiddm_amd import models, nn, noise
+    torch.manual_seed(42)                                    # --seed default, src/mnist_exm.py:112
+    net = nn.QNN_noise(IMG * IMG, N_QUBITS, QDEPTH)
+    diff = models.Diffusion(net=net, noise_f=noise.add_normal_noise_multiple, prediction_goal="data",
+                            shape=(IMG, IMG), loss=torch.nn.MSELoss()).to(dev, dtype=torch.double)
+    return diff.eval()
+
+
+def make_step(diff, x0, use_graph):
+    """Returns (step_fn, state) where step_fn() advances ``state`` by one denoise step."""
+    x = x0.clone()
+
+    def eager():
+        with torch.no_grad():
+            x.copy_(diff.denoise_step(x))
+
+    if not use_graph:
+        return eager, x
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            eager()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        eager()
+    return graph.replay, x
+
+
+def time_circuit_kernel(net, batch, dev, launches=200):
+    """Average duration of the dominant kernel (circuit_kernel<float, 8>) measured with HIP
+    events on the stream it is launched on: `launches` back-to-back launches inside one
+    hipGraph replay, same arguments as in the timed step."""
+    from qiddm_amd.circuit import Circuit, prepare_gates, run_forward
+    circ = Circuit(n_qubits=N_QUBITS, encoding="rz", imprimitive="CZ", measure="expz", sel_layers=QDEPTH)
+    angles = net.weights.detach().reshape(circ.angles_shape)
+    x = torch.randn(batch, N_QUBITS, device=dev)
+    table = prepare_gates(circ, angles, "f32")
+    out = run_forward(circ, x, angles, "f32", table=table)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run_forward(circ, x, angles, "f32", table=table)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(launches):
+            out = run_forward(circ, x, angles, "f32", table=table)
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    avg_us = e0.elapsed_time(e1) * 1e3 / (reps * launches)
+    return avg_us, circ
+
+
+def cpu_baseline(diff, x0_cpu, budget_s):
+    """The oracle (CPU restatement of default.qubit's per-gate complex128 update, batched) on the
+    same denoise step, all host threads, bounded sample."""
+    from oracle import circuits as oc
+    sd = {k[4:]: v.detach().cpu() for k, v in diff.state_dict().items()}
+
+    def net(t):
+        return oc.qnn_forward(t, sd["linear_down.weight"], sd["linear_down.bias"], sd["weights"],
+                              sd["linear_up.weight"], sd["linear_up.bias"])
+
+    x = x0_cpu
+    with torch.no_grad():
+        net(x)                                   # warm-up
+        n, t0 = 0, time.perf_counter()
+        while True:
+            x = net(x)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 1000:
+                break
+    return n * x.shape[0] / el, n, el
+
+
+def load_pmc_traffic(kernel_substr, batch):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        rec = json.load(open(path))
+        for r in rec.get("kernels", []):
+            if kernel_substr in r["kernel"] and r.get("batch") == batch:
+                return r["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+    return None
+
+
+def main():
+    args = parse()
+    world, rank, local = init_dist(args)
+    dev = torch.device("cuda", local)
+    from qiddm_amd import _capi
+    _capi.lib()                                                  # fail loudly if the extension is missing
+
+    diff = build_model(dev)
+    torch.manual_seed(1000 + rank)
+    x0 = (torch.rand(args.batch, 1, IMG, IMG, dtype=torch.double) * 0.75 + 0.5)
+    step, _state = make_step(diff, x0.to(dev), use_graph=not args.no_graph)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    images = world * args.batch * args.steps
+    value = images / elapsed
+    result = None
+    if rank == 0:
+        kern_us, circ = time_circuit_kernel(diff.net, args.batch, dev)
+        g_per_sample = circ.gate_count()
+        alg_bytes = circ.algorithmic_bytes_per_sample("f32") * args.batch      # per launch
+        achieved = alg_bytes / (kern_us * 1e-6) / 1e9
+        result = {
+            "metric": "denoise-step images/sec, 8-qubit MNIST-28",
+            "value": value,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "MNIST 28x28, 8-qubit qdense QNN_noise(784,8,14), batch 256 per GPU, "
+                                   "one Diffusion.sample body (goal=data) per step",
+                       "batch_per_gpu": args.batch, "global_batch": world * args.batch,
+                       "n_qubits": N_QUBITS, "gates_per_sample": g_per_sample,
+                       "launch": "eager" if args.no_graph else "hipGraph replay",
+                       "parallelism": f"shard{world}"},
+            "gate_apps_per_s": value * g_per_sample,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": load_pmc_traffic("circuit_kernel", args.batch),
+                         "kernel": "qiddm::circuit_kernel<float, 8, false>",
+                         "kernel_avg_us": kern_us,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "note": "algorithmic = (G+1/2)*16*2^n B per sample (SURVEY 8d); the slab lives "
+                                 "in registers, so physical HBM traffic is inputs+outputs only"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            v, n_steps, el = cpu_baseline(diff, x0, args.cpu_seconds)
+            result["cpu_baseline"] = {
+                "value": v, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": f"{n_steps} denoise steps of the same batch-{args.batch} workload in {el:.1f} s "
+                          "(oracle: batched complex128 per-gate torch update)",
+                "gate_apps_per_s": v * g_per_sample}
+            result["speedup_vs_cpu"] = value / v
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

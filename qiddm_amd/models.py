@@ -1,0 +1,100 @@
+"""The denoise loop around the quantum layers (reference src/models.py:8-150)."""
+from __future__ import annotations
+
+import typing
+
+import torch
+
+try:  # progress bars are optional glue
+    import tqdm
+except Exception:  # pragma: no cover
+    tqdm = None
+
+
+class Diffusion(torch.nn.Module):
+    """``Diffusion(net, noise_f, prediction_goal, shape, loss)``.
+
+    * ``train()`` mode: ``diff(x=x, T=tau, verbose=bool)`` runs one training step **including
+      ``.backward()``** (reference src/models.py:67, 99) and returns ``(loss, recon)`` or
+      ``(loss,)``.
+    * ``eval()`` mode: ``diff(x=first_x, n_iters=...)`` == ``diff.sample(...)``.
+    * ``state_dict()`` keys are prefixed ``net.`` (checkpoint contract).
+    """
+
+    def __init__(self, net: torch.nn.Module, noise_f, prediction_goal: str,
+                 shape: typing.Tuple[int, int],
+                 loss: torch.nn.Module = torch.nn.MSELoss(reduction="none")) -> None:
+        super().__init__()
+        self.net = net
+        self.prediction_goal = prediction_goal
+        self.add_noise = noise_f
+        self.width, self.height = shape
+        self.loss = loss
+
+    def forward(self, x=None, **kwargs):
+        if not self.training:
+            return self.sample(first_x=x, **kwargs)
+        if self.prediction_goal == "data":
+            return self.run_training_step_data(x, **kwargs)
+        return self.run_training_step_noise(x, **kwargs)
+
+    # -- training ---------------------------------------------------------------
+    def _noisy_clean_pairs(self, x, T):
+        """(batch*T, 1, W, H) noisy inputs and their one-step-cleaner targets
+        (reference src/models.py:45-63)."""
+        whole = self.add_noise(x, tau=T + 1, decay_mod=3.0).reshape(x.shape[0], T + 1, -1)
+        noisy = whole[:, 1:, :].reshape(-1, 1, self.width, self.height)
+        clean = whole[:, :-1, :].reshape(-1, 1, self.width, self.height)
+        return noisy, clean
+
+    def run_training_step_data(self, x: torch.Tensor, **kwargs):
+        noisy, clean = self._noisy_clean_pairs(x, kwargs["T"])
+        recon = self.net.forward(x=noisy)
+        batch_loss = self.loss(recon, clean)
+        mean = batch_loss.mean()
+        mean.backward()
+        if kwargs.get("verbose", False):
+            return batch_loss.abs(), recon.abs()
+        return (mean.abs(),)
+
+    def run_training_step_noise(self, x: torch.Tensor, **kwargs):
+        noisy, clean = self._noisy_clean_pairs(x, kwargs["T"])
+        predicted = (self.net.forward(x=noisy) - 0.5) * 0.1
+        batch_loss = self.loss(predicted, noisy - clean)
+        mean = batch_loss.mean()
+        mean.backward()
+        if kwargs.get("verbose", False):
+            return batch_loss, torch.clamp(noisy - predicted, 0, 1)
+        return (mean,)
+
+    # -- sampling ------------------------------------------------------------------
+    def denoise_step(self, x, noise_factor=1.0):
+        """One body of the sampling loop (reference src/models.py:127-134): the unit behind
+        BASELINE.json's "denoise-step images/sec"."""
+        predicted = self.net(x)
+        if self.prediction_goal == "data":
+            return predicted
+        return torch.clamp(x - (predicted - 0.5) * 0.1 * noise_factor, 0, 1)
+
+    def sample(self, n_iters, first_x=None, labels=None, show_progress: bool = False,
+               only_last=False, step=1, noise_factor=1.0) -> torch.Tensor:
+        if first_x is None:
+            first_x = torch.rand((10, 1, self.width, self.height))
+        outp = [first_x]
+        iters = range(n_iters)
+        if show_progress and tqdm is not None:
+            iters = tqdm.tqdm(iters)
+        with torch.no_grad():
+            x = first_x
+            for i in iters:
+                x = self.denoise_step(x, noise_factor)
+                if i % step == 0:
+                    outp.append(x)
+        if only_last:
+            return outp[-1]
+        st = torch.stack(outp)                                  # iters batch 1 height width
+        it, b, _, h, w = st.shape
+        return st[:, :, 0].permute(0, 2, 1, 3).reshape(it * h, b * w)   # (iters height) (batch width)
+
+    def save_name(self):
+        return f"{self.net.save_name()}{'_noise' if self.prediction_goal == 'noise' else ''}"

@@ -1,0 +1,73 @@
+"""Quantum convolution (reference nn/qconv.py:8-126, exported as ``QConv2d`` at :307).
+
+Implements the *intended* layer (SURVEY.md finding F3): the reference's
+``forward`` (:71-87) never calls ``self.qnode``, so as checked in it returns
+``ceil(C k^2 / 2)`` post-processed *input patches* instead of ``out_channels``
+circuit outputs and crashes the BatchNorm that follows it in ``unet_simple``.  The
+only meaningful reading -- ``x = self.qnode(x)`` between :78 and :79 -- is what
+runs here:
+
+    unfold -> (+0.1) -> AmplitudeEmbedding(pad 0.5, normalize) ->
+    StronglyEntanglingLayers(pi*tanh(W), CNOT) -> probs -> *D/2, clamp, [::2], [:C_out]
+
+one circuit per output pixel, one wavefront per circuit.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+
+import torch
+
+from .. import qml
+from .qdense import _qw_tanh
+
+
+class QConv2d(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size=(3, 3), padding=1, qdepth=2):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = kernel_size if isinstance(kernel_size, tuple) else (kernel_size, kernel_size)
+        self.padding = padding if isinstance(padding, tuple) else (padding, padding)
+        self.unfold = torch.nn.Unfold(kernel_size=kernel_size, padding=padding).double()
+        wires_for_inp = math.ceil(math.log2(self.kernel_size[0] * self.kernel_size[1] * in_channels))
+        wires_for_out = math.ceil(math.log2(out_channels))
+        self.wires = max(wires_for_inp, wires_for_out, 1)
+        if self.wires > 10:
+            warnings.warn(f"Too many wires ({self.wires}). This might cause performance issues.")
+        template_shape = qml.StronglyEntanglingLayers.shape(n_layers=qdepth, n_wires=self.wires)
+        w = torch.rand(template_shape, dtype=torch.double, requires_grad=True)
+        self.weights = torch.nn.Parameter(w * math.pi - math.pi / 2)
+        self.qdev = qml.device("default.qubit.torch", wires=self.wires)
+        self.qnode = qml.QNode(func=self._circuit, device=self.qdev, cache=True, cachesize=int(1e6),
+                               interface="torch", diff_method="backprop")
+        self.sample_qnode = None
+        self.sample_matrix = None
+
+    def _circuit(self, features):
+        qml.AmplitudeEmbedding(features=features.double(), wires=range(self.wires), pad_with=0.5,
+                               normalize=True)
+        qml.StronglyEntanglingLayers(_qw_tanh(self.weights.double()), wires=range(self.wires))
+        return qml.probs(wires=range(self.wires))
+
+    def _post_process(self, quantum_probs):
+        p = torch.clamp(quantum_probs * quantum_probs.shape[-1] * 0.5, 0.0, 1.0)
+        return p[:, ::2][:, : self.out_channels].double()
+
+    def forward(self, x):
+        b, c, h_in, w_in = x.shape
+        assert c == self.in_channels, f"Expected {self.in_channels} channels, got {c}"
+        h_out = h_in + 2 * self.padding[0] - self.kernel_size[0] + 1
+        w_out = w_in + 2 * self.padding[1] - self.kernel_size[1] + 1
+        cols = self.unfold(x.double())                                   # (b, C k^2, h_out*w_out)
+        feats = cols.transpose(1, 2).reshape(b * h_out * w_out, -1) + 0.1
+        y = self._post_process(self.qnode(feats))                        # ((b h w), C_out)
+        return y.reshape(b, h_out, w_out, -1).permute(0, 3, 1, 2).contiguous()
+
+    def __repr__(self):
+        return (f"QConv2d({self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, "
+                f"padding={self.padding}, wires={self.wires})")
+
+
+_QConv2d_FAST = QConv2d

@@ -1,0 +1,59 @@
+"""The C-ABI library loads and exports every symbol include/qiddm_hip.h declares
+(no compute calls: there is no GPU on the build box)."""
+import ctypes
+import os
+import re
+
+from qiddm_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "qiddm_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qiddm_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared() == sorted(_capi.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    for name in _declared():
+        assert getattr(hip_lib, name) is not None, name
+
+
+def test_introspection_calls_need_no_gpu(hip_lib):
+    assert hip_lib.qiddm_abi_version() == 1
+    assert hip_lib.qiddm_max_qubits() == 10
+    from qiddm_amd.circuit import Circuit
+    # SURVEY section 8a gate counts
+    cases = [
+        (Circuit(8, "rz", "CZ", "expz", 1, 1, 14), 232, 112),
+        (Circuit(8, "rz", "CZ", "expz", 2, 6, 2), 480, 192),
+        (Circuit(10, "rz", "CZ", "probs", 2, 9, 2), 900, 360),
+        (Circuit(10, "amplitude", "CNOT", "probs", 1, 1, 60, n_features=784, pad_with=0.1), 1201, 600),
+        (Circuit(4, "rz", "CZ", "expz", 1, 1, 2), 20, 8),
+    ]
+    for circ, g, rot in cases:
+        cs = circ.c_struct("f32")
+        assert hip_lib.qiddm_gate_count(ctypes.byref(cs)) == g == circ.gate_count()
+        assert hip_lib.qiddm_num_rot_gates(ctypes.byref(cs)) == rot
+        assert hip_lib.qiddm_gate_table_elems(ctypes.byref(cs)) == rot * 56
+    cs = cases[1][0].c_struct("f32")
+    assert hip_lib.qiddm_num_shift_replicas(ctypes.byref(cs), 0) == 6 * 192
+    assert hip_lib.qiddm_num_shift_replicas(ctypes.byref(cs), 1) == 6 * 192 + 2 * 6 * 8
+
+
+def test_invalid_descriptors_are_rejected_with_a_reason(hip_lib):
+    from qiddm_amd.circuit import Circuit
+    cs = Circuit(12, "rz").c_struct("f32")
+    assert hip_lib.qiddm_gate_count(ctypes.byref(cs)) == -1
+    assert b"exceeds" in hip_lib.qiddm_last_error()
+    cs = Circuit(2, "amplitude", "CNOT", "probs", n_features=5).c_struct("f32")
+    assert hip_lib.qiddm_gate_count(ctypes.byref(cs)) == -1
+    assert b"Features must be of length 4 or smaller" in hip_lib.qiddm_last_error()
+    cs = Circuit(3).c_struct("f32")
+    cs.sel_layers = 0
+    assert hip_lib.qiddm_num_rot_gates(ctypes.byref(cs)) == -1

@@ -1,0 +1,208 @@
+"""GPU parity of the layer classes (the reference's ``nn`` namespace) and of the denoise loop
+against the CPU oracle restatement of the same reference lines, on identical seeds."""
+import os
+
+import pytest
+import torch
+
+from oracle import circuits as oc
+from oracle import diffusion as odf
+
+pytestmark = pytest.mark.gpu
+
+CK = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "checkpoints")
+DEV = "cuda"
+
+
+def _img(b, w, seed, c=1):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(b, c, w, w, generator=g, dtype=torch.float64)
+
+
+@pytest.mark.parametrize("cfg", [(64, 4, 2, 8), (784, 8, 14, 28)])
+def test_qnn_noise_forward(cfg):
+    """Row A1.  C1: QNN_noise(64,4,2); C2: QNN_noise(784,8,14)."""
+    from qiddm_amd import nn
+    dim, n, depth, w = cfg
+    torch.manual_seed(42)
+    m = nn.QNN_noise(dim, n, depth).to(DEV)
+    x = _img(33, w, 1)
+    with torch.no_grad():
+        got = m(x.to(DEV)).cpu()
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    ref = oc.qnn_forward(x, sd["linear_down.weight"], sd["linear_down.bias"], sd["weights"],
+                         sd["linear_up.weight"], sd["linear_up.bias"])
+    assert got.shape == x.shape and got.dtype == torch.float64
+    assert torch.allclose(got, ref, atol=5e-5, rtol=1e-4), (got - ref).abs().max()
+
+
+def test_qnn_noise_real_checkpoint():
+    """Trained weights shipped with the reference (results/emnist.zip)."""
+    from qiddm_amd import models, nn, noise
+    ck = torch.load(os.path.join(CK, "QNN_linear_features=8_qdepth=6_add_noise=0_noise_2.pt"),
+                    weights_only=True, map_location="cpu")
+    net = nn.QNN_noise(784, 8, 6)
+    diff = models.Diffusion(net, noise.add_normal_noise_multiple, "noise", (28, 28)).to(DEV, dtype=torch.double)
+    diff.load_state_dict(ck["model_state_dict"])
+    x = _img(10, 28, 3) * 0.75 + 0.5
+    sd = {k[4:]: v for k, v in ck["model_state_dict"].items()}
+    ref_net = lambda t: oc.qnn_forward(t, sd["linear_down.weight"], sd["linear_down.bias"], sd["weights"],
+                                       sd["linear_up.weight"], sd["linear_up.bias"])
+    diff.eval()
+    got = diff.sample(first_x=x.to(DEV), n_iters=3).cpu()
+    ref = odf.sample(ref_net, x, 3, goal="noise")
+    assert got.shape == (4 * 28, 10 * 28)
+    assert torch.allclose(got, ref, atol=1e-4), (got - ref).abs().max()
+
+
+@pytest.mark.parametrize("cfg,fused", [((64, 4, 2, 1, 8), True), ((784, 8, 6, 2, 28), True),
+                                        ((784, 6, 14, 2, 28), False)])
+def test_qiddm_ll_noise_forward(cfg, fused):
+    """Row A2: QIDDM_LL_noise; fused multi-round launch (no_grad) and the per-round QNode path."""
+    from qiddm_amd import nn
+    dim, n, L, N, w = cfg
+    torch.manual_seed(7)
+    m = nn.QIDDM_LL_noise(dim, n, L, N).to(DEV, dtype=torch.double)
+    x = _img(21, w, 2)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    ref = oc.qiddm_ll_forward(x, sd["linear_down.weight"], sd["linear_down.bias"], sd["weights1"],
+                              sd["linear_up.weight"], sd["linear_up.bias"])
+    if fused:
+        with torch.no_grad():
+            got = m(x.to(DEV)).cpu()
+    else:
+        got = m(x.to(DEV)).detach().cpu()
+    assert torch.allclose(got, ref, atol=5e-5, rtol=1e-4), (got - ref).abs().max()
+
+
+def test_detach_quantum_switch():
+    """F1: as written only linear_up learns; detach_quantum=False lets parameter-shift
+    gradients reach weights1 and linear_down -- and they match autograd through the oracle."""
+    from qiddm_amd import nn, set_default_precision
+    torch.manual_seed(3)
+    x = _img(6, 8, 4)
+    m = nn.QIDDM_LL_noise(64, 4, 2, 2).to(DEV, dtype=torch.double)
+    m(x.to(DEV)).square().mean().backward()
+    assert m.weights1.grad is None and m.linear_down.weight.grad is None
+    assert m.linear_up.weight.grad is not None
+    set_default_precision("f64")
+    try:
+        m2 = nn.QIDDM_LL_noise(64, 4, 2, 2, detach_quantum=False).to(DEV, dtype=torch.double)
+        m2.load_state_dict(m.state_dict())
+        m2(x.to(DEV)).square().mean().backward()
+    finally:
+        set_default_precision("f32")
+    ps = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.named_parameters()}
+    ref = oc.qiddm_ll_forward(x, ps["linear_down.weight"], ps["linear_down.bias"], ps["weights1"],
+                              ps["linear_up.weight"], ps["linear_up.bias"])
+    ref.square().mean().backward()
+    for k, p in m2.named_parameters():
+        assert torch.allclose(p.grad.cpu(), ps[k].grad, atol=1e-9), k
+
+
+def test_differn_from_reduced_real_checkpoint():
+    """Row A3 from the post-PCA tensor on (F4), with the Ray-Tune checkpoint's weights."""
+    from qiddm_amd import nn
+    ck = torch.load(os.path.join(CK, "differN_noise=9_N=2_w28_h28_noise_0.035069821502010365_0.25081669882500224.pt"),
+                    weights_only=True, map_location="cpu")
+    m = nn.differN_noise_befor(28, 9, 2)
+    m.load_state_dict({"weights": ck["model_state_dict"]["net.weights"]})
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(11)
+    red = torch.randn(17, 10, generator=g) * 2.0
+    ref = oc.differn_from_reduced(red, ck["model_state_dict"]["net.weights"], (28, 28))
+    with torch.no_grad():
+        fused = m.forward_from_reduced(red.to(DEV)).cpu()
+    per_round = m.forward_from_reduced(red.to(DEV)).detach().cpu()
+    # post-processed pixels are probabilities * 784: scale the tolerance accordingly
+    assert torch.allclose(fused, ref, atol=2e-2), (fused - ref).abs().max()
+    assert torch.allclose(per_round, ref, atol=2e-2), (per_round - ref).abs().max()
+    assert fused.shape == (17, 1, 28, 28)
+
+
+def test_differn_full_forward_with_host_pca():
+    from qiddm_amd import nn
+    torch.manual_seed(0)
+    m = nn.differN_noise(8, 3, 2).to(DEV)
+    x = _img(20, 8, 5)
+    with torch.no_grad():
+        y = m(x.to(DEV))
+    red = m.reduce(x)
+    ref = oc.differn_from_reduced(red.cpu(), m.weights.detach().cpu(), (8, 8))
+    assert torch.allclose(y.cpu(), ref, atol=2e-3)
+    with pytest.raises(ValueError):      # fewer rows than PCA components (sklearn, F4)
+        m(x[:3].to(DEV))
+
+
+@pytest.mark.parametrize("cls_name,wmap", [("QDenseUndirected_old", "qw_tanh"), ("QDenseUndirected_old_noise", "tanh")])
+def test_qdense_undirected_forward(cls_name, wmap):
+    """Row A4 at C1 size (8x8, n=6) and the shipped 28x28 / 60-layer checkpoint."""
+    from qiddm_amd import nn
+    torch.manual_seed(5)
+    m = getattr(nn, cls_name)(12, 8).to(DEV)
+    x = _img(9, 8, 6)
+    with torch.no_grad():
+        got = m(x.to(DEV)).cpu()
+    ref = oc.qdense_undirected_forward(x, m.weights.detach().cpu(), (8, 8), wmap)
+    assert torch.allclose(got, ref, atol=2e-3), (got - ref).abs().max()
+
+
+def test_qdense_real_checkpoint_28():
+    from qiddm_amd import nn
+    ck = torch.load(os.path.join(CK, "QDenseUndirected_old_noise60_w28_h28_noise0_noise_2.pt"),
+                    weights_only=True, map_location="cpu")
+    m = nn.QDenseUndirected_old_noise(60, 28)
+    m.load_state_dict({"weights": ck["model_state_dict"]["net.weights"]})
+    m = m.to(DEV)
+    x = _img(5, 28, 7)
+    with torch.no_grad():
+        got = m(x.to(DEV)).cpu()
+    ref = oc.qdense_undirected_forward(x, ck["model_state_dict"]["net.weights"], (28, 28), "tanh")
+    assert torch.allclose(got, ref, atol=2e-2), (got - ref).abs().max()
+
+
+@pytest.mark.parametrize("cin,cout,k,pad,hw", [(1, 8, 3, 1, 9), (8, 16, 3, 1, 6), (16, 8, 1, 0, 7), (3, 4, 3, 1, 5)])
+def test_qconv2d_forward(cin, cout, k, pad, hw):
+    """Row A5: the intended QConv2d (F3)."""
+    from qiddm_amd import nn
+    torch.manual_seed(8)
+    m = nn.QConv2d(cin, cout, k, pad, 3).to(DEV)
+    x = _img(3, hw, 9, c=cin)
+    with torch.no_grad():
+        got = m(x.to(DEV)).cpu()
+    ref = oc.qconv2d_forward(x, m.weights.detach().cpu(), cout, (k, k), (pad, pad))
+    assert got.shape == ref.shape == (3, cout, hw, hw)
+    assert torch.allclose(got, ref, atol=1e-3), (got - ref).abs().max()
+
+
+def test_unet_simple_runs():
+    """Row A6: UNetUndirectedS(3, 8, 3) end to end (wires 4,7,8 / 5,9 / 4,8)."""
+    from qiddm_amd import nn
+    torch.manual_seed(9)
+    u = nn.UNetUndirectedS(3, 8, 3).to(DEV).eval()
+    with torch.no_grad():
+        y = u(_img(2, 28, 10).to(DEV))
+    assert y.shape == (2, 1, 28, 28) and y.dtype == torch.float64 and torch.isfinite(y).all()
+
+
+def test_diffusion_training_step_on_device():
+    """Row A7 with a quantum net: loss + recon of one training step vs the oracle loop."""
+    from qiddm_amd import models, nn, noise
+    torch.manual_seed(12)
+    net = nn.QNN_noise(64, 4, 2)
+    diff = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (8, 8),
+                            torch.nn.MSELoss()).to(DEV, dtype=torch.double)
+    diff.train()
+    x = _img(4, 8, 13).reshape(4, 64)
+    torch.manual_seed(77)
+    nz = torch.normal(mean=0.5, std=0.2, size=(4, 64))
+    torch.manual_seed(77)
+    loss, recon = diff(x=x.to(DEV), T=10, verbose=True)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    ref_net = lambda t: oc.qnn_forward(t, sd["linear_down.weight"], sd["linear_down.bias"], sd["weights"],
+                                       sd["linear_up.weight"], sd["linear_up.bias"])
+    ref_loss, ref_recon = odf.training_loss(ref_net, x, 10, (8, 8), "data", noise=nz)
+    assert recon.shape == (40, 1, 8, 8)
+    assert torch.allclose(recon.detach().cpu(), ref_recon.abs(), atol=5e-5)
+    assert abs(loss.item() - ref_loss.item()) < 1e-5
+    assert net.linear_up.weight.grad is not None and net.weights.grad is None   # F1

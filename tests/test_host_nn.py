@@ -1,0 +1,165 @@
+"""Host mirror of the reference's ``nn`` namespace: constructor signatures, parameter
+names / shapes, ``save_name()`` strings, checkpoint compatibility with the files the
+reference ships, circuit descriptors -- everything that needs no GPU -- plus the
+"fails loudly on CPU" contract."""
+import os
+
+import pytest
+import torch
+
+from qiddm_amd import models, nn, noise, qml
+from qiddm_amd.circuit import Circuit
+
+CK = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "checkpoints")
+
+
+def _load(name):
+    return torch.load(os.path.join(CK, name), weights_only=True, map_location="cpu")
+
+
+def test_driver_style_construction():
+    """``eval(f"nn.{name}")(*params)`` with digit strings cast to int (src/mnist_exm.py:420-424)."""
+    for model_args in (["QIDDM_LL_noise", 28 * 28, "6", "14", "2"], ["QNN_noise", 28 * 28, "8", "14"],
+                       ["QNN_noise", "28 * 28", "8", "14"], ["differN_noise", 28, "9", "2"],
+                       ["QDenseUndirected_old_noise", "60", "28"], ["QIDDM_PL_noise", 64, "4", "2", "1"],
+                       ["UNetUndirectedS", "3", "8", "3"], ["UNetUndirected", "3", "8", "0"]):
+        params = [int(a) if isinstance(a, str) and a.isdigit() else a for a in model_args[1:]]
+        net = eval(f"nn.{model_args[0]}")(*params)
+        assert isinstance(net.save_name(), str) and repr(net)
+
+
+@pytest.mark.parametrize("ctor,args,fname,prefix", [
+    (nn.QNN_noise, (784, 8, 6), "QNN_linear_features=8_qdepth=6_add_noise=0_noise_2.pt",
+     "QNN_linear_features=8_qdepth=6_add_noise=0"),
+    (nn.QIDDM_PL_noise, (784, 8, 6, 2), "QIDDM_PL_noise=8_L=6_N=2_noise_2.pt", "QIDDM_PL_noise=8_L=6_N=2"),
+    (nn.QDenseUndirected_old_noise, (60, 28), "QDenseUndirected_old_noise60_w28_h28_noise0_noise_2.pt",
+     "QDenseUndirected_old_noise60_w28_h28_noise0"),
+    (nn.differN_old_pca, (28, 15, 2), "differN_old_pca=15_N=2_w28_h28_noise0_noise_2.pt", None),
+    (nn.differN_noise_befor, (28, 9, 2),
+     "differN_noise=9_N=2_w28_h28_noise_0.035069821502010365_0.25081669882500224.pt",
+     "differN_noise=9_N=2_w28_h28"),
+    (nn.UNetUndirected, (3, 8, 0), "unet_undirected_d3_s8_d0_noise_2.pt", "unet_undirected_d3_s8_d0"),
+])
+def test_reference_checkpoints_load(ctor, args, fname, prefix):
+    """state_dict keys / shapes equal the shipped checkpoints' (SURVEY.md section 4), and the file
+    name is ``<save_name()>_noise_<label>.pt`` (src/models.py:149-150, src/mnist_exm.py:189)."""
+    ck = _load(fname)
+    net = ctor(*args)
+    diff = models.Diffusion(net, noise.add_normal_noise_multiple, "noise", (28, 28),
+                            torch.nn.MSELoss()).to(dtype=torch.double)
+    missing, unexpected = diff.load_state_dict(ck["model_state_dict"], strict=True)
+    assert not missing and not unexpected
+    for k, v in ck["model_state_dict"].items():
+        assert torch.equal(diff.state_dict()[k], v)
+    if prefix is not None:
+        assert fname.startswith(diff.save_name()) and diff.save_name() == prefix + "_noise"
+    assert len(ck["loss_values"]) == ck["epochs"]
+
+
+def test_parameter_contract():
+    m = nn.QNN_noise(784, 8, 14)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {
+        "linear_down.weight": (8, 784), "linear_down.bias": (8,), "linear_up.weight": (784, 8),
+        "linear_up.bias": (784,), "weights": (14, 8, 3)}
+    assert all(v.dtype == torch.float64 for v in m.state_dict().values())
+    assert sum(p.numel() for p in m.parameters()) == 13672
+    ll = nn.QIDDM_LL_noise(784, 6, 14, 2)
+    assert tuple(ll.weights1.shape) == (2, 14, 2, 6, 3) and ll.weights1.dtype == torch.float32
+    assert ll.save_name() == "QIDDM_LL_noise=6_L=14_N=2"
+    assert nn.QIDDM_LL_relu_noise(784, 6, 14, 2).save_name() == ll.save_name()
+    assert nn.QIDDM_L is nn.QIDDM_LL_noise
+    d = nn.differN_noise(28, 9, 2)
+    assert d.wires == 10 and tuple(d.weights.shape) == (2, 9, 2, 10, 3)
+    assert d.save_name() == "differN_old_pca=9_N=2_w28_h28_noise0"
+    assert nn.differN_noise((8, 8), 4, 2).wires == 6
+    q = nn.QDenseUndirected_old(60, 28)
+    assert q.wires == 10 and tuple(q.weights.shape) == (60, 10, 3)
+    assert q.save_name() == "QDenseUndirected_old60_w28_h28"
+    assert nn.QNN(64, 4, 2).save_name() == "QNN_linear_features=4_qdepth=2"
+    assert nn.QNN_A(3, 8).save_name() == "QNN_A3_w8_h8_noise0"
+    assert nn.QIDDM_PL(64, 4, 2, 1).save_name() == "QIDDM_PL=4_L=2_N=1"
+
+
+def test_seeded_construction_is_reproducible():
+    torch.manual_seed(42)
+    a = nn.QNN_noise(784, 8, 14)
+    torch.manual_seed(42)
+    b = nn.QNN_noise(784, 8, 14)
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    # weights are drawn AFTER the two linear layers, as randn * 0.4 in float64 (nn/qdense.py:232-241)
+    torch.manual_seed(42)
+    torch.nn.Linear(784, 8, dtype=torch.double)
+    torch.nn.Linear(8, 784, dtype=torch.double)
+    assert torch.equal(a.weights.detach(), torch.randn(14, 8, 3, dtype=torch.double) * 0.4)
+
+
+def test_qconv_wire_rule_and_unet_wiring():
+    """wires = max(ceil(log2 k^2 C_in), ceil(log2 C_out), 1) (nn/qconv.py:24-28); SURVEY 3.3."""
+    assert nn.QConv2d(1, 8, 3, 1, 3).wires == 4
+    assert nn.QConv2d(8, 16, 3, 1, 3).wires == 7
+    u = nn.UNetUndirectedS(3, 8, 3)
+    assert [b.net[0].wires for b in u.down_blocks] == [4, 7, 8]
+    assert [(b.up_conv[1].wires, b.net[0].wires) for b in u.up_blocks] == [(5, 9), (4, 8)]
+    assert isinstance(u.final_conv, torch.nn.Conv2d)
+    assert u.save_name() == "unet_s_undirected_d3_s8_d3"
+    w = nn.QConv2d(1, 8, 3, 1, 3).weights
+    assert w.dtype == torch.float64 and w.min() >= -torch.pi / 2 and w.max() <= torch.pi / 2
+    with pytest.warns(UserWarning, match="Too many wires"):
+        assert nn.QConv2d(256, 256, 3, 1, 1).wires == 12
+    with pytest.raises(AssertionError, match="Depth must be greater than 0"):
+        nn.UNetUndirected(0, 8, 0)
+
+
+def test_classical_unet_runs_on_cpu():
+    """qdepth=0 never touches the quantum engine (reference nn/unet.py:21-24)."""
+    u = nn.UNetUndirected(3, 8, 0)
+    y = u(torch.rand(2, 1, 28, 28))
+    assert y.shape == (2, 1, 28, 28) and y.dtype == torch.float64
+
+
+def test_qnode_tape_compiles_to_descriptor():
+    """Tracing ``_circuit`` needs no GPU; execution does."""
+    from qiddm_amd.qml import _compile
+    m = nn.QIDDM_LL_noise(784, 8, 6, 2)
+    x = torch.rand(5, 8)
+    tape, ret = m.qnode._trace((x, m.weights1[0]), {})
+    circ, xs, angles, batched, as_list = _compile(tape, ret, 8, m.qdev)
+    assert circ == Circuit(8, "rz", "CZ", "expz", 1, 6, 2) and batched and as_list
+    assert tuple(angles.shape) == (1, 6, 2, 8, 3) and torch.equal(xs, x)
+    d = nn.QDenseUndirected_old(3, 8)
+    tape, ret = d.qnode._trace((torch.rand(4, 64),), {})
+    circ, xs, angles, batched, _ = _compile(tape, ret, 6, d.qdev)
+    assert circ == Circuit(6, "amplitude", "CNOT", "probs", 1, 1, 3, n_features=64, pad_with=0.1)
+    assert torch.allclose(angles[0, 0], torch.pi * torch.tanh(d.weights))       # qw_map.tanh
+    a = nn.QNN_A(2, 4)
+    tape, ret = a.qnode._trace((torch.rand(3, 4, dtype=torch.double),), {})
+    assert _compile(tape, ret, 4, a.qdev)[0] == Circuit(4, "ry", "CNOT", "probs", 1, 1, 2)
+    # per-sample call signature of the lightning classes: 1-D inputs -> unbatched
+    tape, ret = m.qnode._trace((x[0], m.weights1[1]), {})
+    assert _compile(tape, ret, 8, m.qdev)[3] is False
+
+
+def test_noise_channels_raise_like_a_pure_state_device():
+    m = nn.QNN_noise(64, 4, 2, add_noise=2)
+    with pytest.raises(qml.DeviceError, match="AmplitudeDamping not supported on device lightning.qubit"):
+        m.qnode(torch.rand(3, 4, dtype=torch.double), m.weights)
+    # add_noise=1 on differN is PhaseShift right before probs: compiles (and is a no-op, K9)
+    from qiddm_amd.qml import _compile
+    d = nn.differN_noise(8, 2, 1, add_noise=1)
+    tape, ret = d.qnode._trace((torch.rand(3, 6), d.weights[0]), {})
+    assert _compile(tape, ret, 6, d.qdev)[0].n_blocks == 2
+    with pytest.raises(qml.DeviceError):
+        qml.device("no.such.device", wires=2)
+    with pytest.raises(qml.QuantumFunctionError):
+        qml.QNode(lambda: None, qml.device("default.qubit", wires=1), diff_method="finite-diff")
+
+
+def test_quantum_forward_on_cpu_fails_loudly():
+    m = nn.QNN_noise(64, 4, 2)
+    if torch.cuda.is_available():
+        pytest.skip("CPU-box contract")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.rand(2, 1, 8, 8, dtype=torch.double))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        nn.QConv2d(1, 8, 3, 1, 2)(torch.rand(1, 1, 5, 5))
