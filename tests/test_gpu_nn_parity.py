@@ -179,7 +179,8 @@ def test_unet_simple_runs():
     """Row A6: UNetUndirectedS(3, 8, 3) end to end (wires 4,7,8 / 5,9 / 4,8)."""
     from qiddm_amd import nn
     torch.manual_seed(9)
-    u = nn.UNetUndirectedS(3, 8, 3).to(DEV).eval()
+    # the drivers cast the whole model to double (src/mnist_exm.py:449); BatchNorm2d is float32 otherwise
+    u = nn.UNetUndirectedS(3, 8, 3).to(DEV, dtype=torch.double).eval()
     with torch.no_grad():
         y = u(_img(2, 28, 10).to(DEV))
     assert y.shape == (2, 1, 28, 28) and y.dtype == torch.float64 and torch.isfinite(y).all()
