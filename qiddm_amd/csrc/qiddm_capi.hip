@@ -61,8 +61,18 @@ int check_circuit(const qiddm_circuit_t* c) {
   return QIDDM_OK;
 }
 
+struct Ptrs {
+  const void* inputs = nullptr;
+  const void* table = nullptr;
+  void* out = nullptr;
+  const void* gout = nullptr;
+  void* dots = nullptr;
+};
+
+constexpr size_t kMaxLds = 160 * 1024;  // per-workgroup LDS on gfx950
+
 template <typename T, int N, bool SHIFT>
-int launch(const qiddm::KParams& p, int64_t n_replicas, hipStream_t stream) {
+int launch(const Ptrs& ptr, const qiddm::KScalars& p, int64_t n_replicas, hipStream_t stream) {
   using L = qiddm::Layout<N>;
   using S = qiddm::Smem<T, N>;
   const int64_t groups = (p.batch + L::SPW - 1) / L::SPW;
@@ -72,8 +82,24 @@ int launch(const qiddm::KParams& p, int64_t n_replicas, hipStream_t stream) {
   const int64_t cap = SHIFT ? 1024 : 4096;
   if (bx > cap) bx = cap;
   dim3 grid((unsigned)bx, SHIFT ? (unsigned)n_replicas : 1u, 1u);
-  const size_t smem = S::bytes(p.imprimitive == QIDDM_IMP_CNOT);
-  hipLaunchKernelGGL((qiddm::circuit_kernel<T, N, SHIFT>), grid, dim3(qiddm::kBlock), smem, stream, p);
+  const int64_t n_rot = (int64_t)p.n_rounds * p.n_blocks * p.sel_layers * N;
+  const size_t smem = S::bytes(n_rot, p.imprimitive == QIDDM_IMP_CNOT);
+  if (smem > kMaxLds)
+    return fail(QIDDM_ERR_UNSUPPORTED,
+                "circuit with %lld Rot gates needs %zu B of LDS for its gate table (limit %zu)",
+                (long long)n_rot, smem, kMaxLds);
+  auto kern = qiddm::circuit_kernel<T, N, SHIFT>;
+  static bool big_lds_enabled = false;  // benign race: the attribute call is idempotent
+  if (smem > 48 * 1024 && !big_lds_enabled) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    if (ea != hipSuccess)
+      return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
+    big_lds_enabled = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(qiddm::kBlock), smem, stream, static_cast<const T*>(ptr.inputs),
+                     static_cast<const T*>(ptr.table), static_cast<T*>(ptr.out),
+                     static_cast<const T*>(ptr.gout), static_cast<T*>(ptr.dots), p);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess)
     return fail(QIDDM_ERR_LAUNCH, "circuit_kernel<n=%d> launch failed: %s", N, hipGetErrorString(e));
@@ -81,24 +107,24 @@ int launch(const qiddm::KParams& p, int64_t n_replicas, hipStream_t stream) {
 }
 
 template <typename T, bool SHIFT>
-int dispatch_n(int n, const qiddm::KParams& p, int64_t n_replicas, hipStream_t stream) {
+int dispatch_n(int n, const Ptrs& ptr, const qiddm::KScalars& p, int64_t n_replicas, hipStream_t stream) {
   switch (n) {
-    case 1: return launch<T, 1, SHIFT>(p, n_replicas, stream);
-    case 2: return launch<T, 2, SHIFT>(p, n_replicas, stream);
-    case 3: return launch<T, 3, SHIFT>(p, n_replicas, stream);
-    case 4: return launch<T, 4, SHIFT>(p, n_replicas, stream);
-    case 5: return launch<T, 5, SHIFT>(p, n_replicas, stream);
-    case 6: return launch<T, 6, SHIFT>(p, n_replicas, stream);
-    case 7: return launch<T, 7, SHIFT>(p, n_replicas, stream);
-    case 8: return launch<T, 8, SHIFT>(p, n_replicas, stream);
-    case 9: return launch<T, 9, SHIFT>(p, n_replicas, stream);
-    case 10: return launch<T, 10, SHIFT>(p, n_replicas, stream);
+    case 1: return launch<T, 1, SHIFT>(ptr, p, n_replicas, stream);
+    case 2: return launch<T, 2, SHIFT>(ptr, p, n_replicas, stream);
+    case 3: return launch<T, 3, SHIFT>(ptr, p, n_replicas, stream);
+    case 4: return launch<T, 4, SHIFT>(ptr, p, n_replicas, stream);
+    case 5: return launch<T, 5, SHIFT>(ptr, p, n_replicas, stream);
+    case 6: return launch<T, 6, SHIFT>(ptr, p, n_replicas, stream);
+    case 7: return launch<T, 7, SHIFT>(ptr, p, n_replicas, stream);
+    case 8: return launch<T, 8, SHIFT>(ptr, p, n_replicas, stream);
+    case 9: return launch<T, 9, SHIFT>(ptr, p, n_replicas, stream);
+    case 10: return launch<T, 10, SHIFT>(ptr, p, n_replicas, stream);
     default: return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d not instantiated", n);
   }
 }
 
-qiddm::KParams make_params(const qiddm_circuit_t* c) {
-  qiddm::KParams p;
+qiddm::KScalars make_params(const qiddm_circuit_t* c) {
+  qiddm::KScalars p;
   std::memset(&p, 0, sizeof(p));
   p.encoding = c->encoding;
   p.imprimitive = c->imprimitive;
@@ -191,16 +217,17 @@ int qiddm_forward(const qiddm_circuit_t* c, const void* inputs, int64_t batch, i
   if (out_ld < out_cols(c))
     return fail(QIDDM_ERR_INVALID, "out_ld=%lld < %lld output columns", (long long)out_ld,
                 (long long)out_cols(c));
-  qiddm::KParams p = make_params(c);
-  p.inputs = inputs;
-  p.table = gate_table;
-  p.out = out;
+  qiddm::KScalars p = make_params(c);
+  Ptrs ptr;
+  ptr.inputs = inputs;
+  ptr.table = gate_table;
+  ptr.out = out;
   p.in_ld = in_ld;
   p.out_ld = out_ld;
   p.batch = batch;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  return c->dtype == QIDDM_F32 ? dispatch_n<float, false>(c->n_qubits, p, 0, st)
-                               : dispatch_n<double, false>(c->n_qubits, p, 0, st);
+  return c->dtype == QIDDM_F32 ? dispatch_n<float, false>(c->n_qubits, ptr, p, 0, st)
+                               : dispatch_n<double, false>(c->n_qubits, ptr, p, 0, st);
 }
 
 int qiddm_forward_shifted(const qiddm_circuit_t* c, const void* inputs, int64_t batch, int64_t in_ld,
@@ -230,18 +257,19 @@ int qiddm_forward_shifted(const qiddm_circuit_t* c, const void* inputs, int64_t 
   if (g_ld < out_cols(c))
     return fail(QIDDM_ERR_INVALID, "g_ld=%lld < %lld output columns", (long long)g_ld,
                 (long long)out_cols(c));
-  qiddm::KParams p = make_params(c);
-  p.inputs = inputs;
-  p.table = gate_table;
-  p.gout = grad_out;
-  p.dots = dots;
+  qiddm::KScalars p = make_params(c);
+  Ptrs ptr;
+  ptr.inputs = inputs;
+  ptr.table = gate_table;
+  ptr.gout = grad_out;
+  ptr.dots = dots;
   p.in_ld = in_ld;
   p.g_ld = g_ld;
   p.batch = batch;
   p.first_replica = (int32_t)first_replica;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  return c->dtype == QIDDM_F32 ? dispatch_n<float, true>(c->n_qubits, p, n_replicas, st)
-                               : dispatch_n<double, true>(c->n_qubits, p, n_replicas, st);
+  return c->dtype == QIDDM_F32 ? dispatch_n<float, true>(c->n_qubits, ptr, p, n_replicas, st)
+                               : dispatch_n<double, true>(c->n_qubits, ptr, p, n_replicas, st);
 }
 
 }  // extern "C"

@@ -1,13 +1,25 @@
-// qsim_fused.h -- fused whole-circuit statevector kernels for gfx950 (CDNA4).
+// qsim_fused.h -- fused whole-circuit statevector engine for gfx950 (CDNA4).
 //
 // One wavefront (64 lanes) owns the complete 2^n-amplitude slab of a sample in
 // registers for the whole circuit (n <= 10): amplitude index k = (r << LB) | sub
 // with sub = lane bits (LB = min(n, 6)) and r = register index (R = 2^(n-LB)
-// complex amplitudes per lane).  For n < 6 a wave carries 64 / 2^n samples.
-// Wire w is bit q = n-1-w of k.  A gate on a register bit is pure VALU work; a
-// gate on a lane bit pairs lane l with l ^ 2^q through cross-lane moves (DPP /
-// ds_swizzle / permlane -- never LDS memory).  CZ rings are precomputed sign
-// masks, CNOT rings a GF(2)-linear scatter through a per-wave LDS scratch slab.
+// complex amplitudes per lane, each a packed (re, im) register pair so that the
+// complex arithmetic issues as v_pk_fma_f32).  For n < 6 a wave carries 64/2^n
+// samples.  Wire w is bit q = n-1-w of k.
+//
+//   * gate on a register bit : pure packed-FMA work, 8 v_pk_fma per amplitude pair
+//   * gate on a lane bit     : partner amplitude fetched with VALU cross-lane moves
+//                              (DPP quad_perm / row_ror / row_half_mirror,
+//                              v_permlane16_swap, v_permlane32_swap -- no LDS
+//                              round trip), 4 v_pk_fma per amplitude
+//   * gate matrices          : staged once per workgroup in LDS as
+//                              [u00, i*u00, u01, i*u01 | u11, i*u11, u10, i*u10] so a lane
+//                              reads the half that matches its bit: no selects
+//   * CZ ring                : precomputed sign-bit masks (LDS)
+//   * CNOT ring              : GF(2)-linear index map, scatter through a per-wave
+//                              LDS slab
+//   * RZ data re-upload      : one per-sample diagonal, built once per round
+//
 // HBM is touched twice per sample: inputs in, probabilities / <Z> out.
 //
 // Replaces the per-gate torch op chains of PennyLane default.qubit.torch and the
@@ -22,30 +34,26 @@ namespace qiddm {
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = kWave * kWavesPerBlock;
-constexpr int kVariants = 7;   // base + six parameter shifts
-constexpr int kGateReals = 8;  // u00 u01 u10 u11 as (re, im)
-
-template <int N>
-struct Layout {
-  static constexpr int LB = N < 6 ? N : 6;   // lane bits
-  static constexpr int R = 1 << (N - LB);    // complex amplitudes per lane
-  static constexpr int LPS = 1 << LB;        // lanes per sample
-  static constexpr int SPW = kWave / LPS;    // samples per wave
-  static constexpr int D = 1 << N;
-  static constexpr int NR = N > 1 ? N - 1 : 1;  // distinct entangler ranges
-};
+constexpr int kVariants = 7;       // global gate table: base + six parameter shifts
+constexpr int kGateReals = 8;      // global gate table: u00 u01 u10 u11 as (re, im)
+constexpr int kLdsGateReals = 16;  // LDS gate table, see above
 
 template <typename T>
-struct alignas(2 * sizeof(T)) C2 {
-  T x, y;
+using V2 = T __attribute__((ext_vector_type(2)));
+
+template <int N, int LBMAX = 6>
+struct Layout {
+  static constexpr int LB = N < LBMAX ? N : LBMAX;  // lane bits
+  static constexpr int R = 1 << (N - LB);           // complex amplitudes per lane
+  static constexpr int LPS = 1 << LB;               // lanes per sample
+  static constexpr int SPW = kWave / LPS;           // samples per wave
+  static constexpr int D = 1 << N;
+  static constexpr int NR = N > 1 ? N - 1 : 1;      // distinct entangler ranges
+  static_assert(R <= 32, "CZ sign masks are packed in one dword per lane");
 };
 
-struct KParams {
-  const void* inputs;
-  const void* table;
-  void* out;
-  const void* gout;  // shifted mode: upstream gradient
-  void* dots;        // shifted mode: (n_replicas, batch)
+// scalar launch parameters (by value in the kernarg segment)
+struct KScalars {
   int64_t in_ld, out_ld, g_ld, batch;
   int32_t first_replica;
   int32_t encoding, imprimitive, measure, n_rounds, n_blocks, sel_layers, n_features;
@@ -53,131 +61,112 @@ struct KParams {
 };
 
 // ---------------------------------------------------------------------------
-// cross-lane exchange: value held by lane (l ^ MASK)
+// small math helpers
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int xlane_i32_dyn(int v, int mask) { return __shfl_xor(v, mask, 64); }
-
-template <int MASK>
-__device__ __forceinline__ int xlane_i32(int v) {
-  if constexpr (MASK == 1) {
-    return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
-  } else if constexpr (MASK == 2) {
-    return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
-  } else if constexpr (MASK == 8) {
-    return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true); // row_ror:8
-  } else if constexpr (MASK == 4) {
-    return __builtin_amdgcn_ds_swizzle(v, 0x101F);             // bitmode xor 4
-  } else if constexpr (MASK == 16) {
-    return __builtin_amdgcn_ds_swizzle(v, 0x401F);             // bitmode xor 16
-  } else {
-    return __shfl_xor(v, MASK, 64);                            // xor 32: ds_bpermute
-  }
+// sin/cos of a float angle with the range reduction done in double: < 1 ulp of float
+// for |x| < 2^30, no scratch, ~30 instructions.
+__device__ __forceinline__ void qsincos(float x, float* s, float* c) {
+  const double xd = (double)x;
+  const double kd = rint(xd * 0.63661977236758134308);  // 2/pi
+  double r = fma(-kd, 1.57079632679489655800e+00, xd);
+  r = fma(-kd, 6.12323399573676603587e-17, r);
+  const double z = r * r;
+  const double w = z * z;
+  // fdlibm k_sinf / k_cosf minimax polynomials on [-pi/4, pi/4], evaluated in double
+  const double sp = (r + (z * r) * (-0.166666666416265235595 + z * 0.0083333293858894631756)) +
+                    (z * r) * w * (-0.000198393348360966317347 + z * 0.0000027183114939898219064);
+  const double cp = ((1.0 + z * -0.499999997251031003120) + w * 0.0416666233237390631894) +
+                    (w * z) * (-0.00138867637746099294692 + z * 0.0000243904487962774090654);
+  const int q = (int)(long long)kd & 3;
+  const double ss = (q & 1) ? cp : sp;
+  const double cc = (q & 1) ? sp : cp;
+  *s = (float)((q & 2) ? -ss : ss);
+  *c = (float)(((q + 1) & 2) ? -cc : cc);
 }
-
-template <int MASK>
-__device__ __forceinline__ float xlane(float v) {
-  return __int_as_float(xlane_i32<MASK>(__float_as_int(v)));
-}
-template <int MASK>
-__device__ __forceinline__ double xlane(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = xlane_i32<MASK>(lo);
-  hi = xlane_i32<MASK>(hi);
-  return __hiloint2double(hi, lo);
-}
-
-// sum over the 2^LB lanes of a sample; every lane ends with the total
-template <typename T, int LB>
-__device__ __forceinline__ T group_sum(T v) {
-  if constexpr (LB > 0) v += xlane<1>(v);
-  if constexpr (LB > 1) v += xlane<2>(v);
-  if constexpr (LB > 2) v += xlane<4>(v);
-  if constexpr (LB > 3) v += xlane<8>(v);
-  if constexpr (LB > 4) v += xlane<16>(v);
-  if constexpr (LB > 5) v += xlane<32>(v);
-  return v;
-}
-
-__device__ __forceinline__ void qsincos(float x, float* s, float* c) { sincosf(x, s, c); }
 __device__ __forceinline__ void qsincos(double x, double* s, double* c) { sincos(x, s, c); }
 __device__ __forceinline__ float qsqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double qsqrt(double x) { return sqrt(x); }
 
-__device__ __forceinline__ float flip_sign(float v, uint32_t bit) {
-  return __int_as_float(__float_as_int(v) ^ (int)(bit << 31));
+template <typename T>
+__device__ __forceinline__ V2<T> bcast(T v) {
+  return V2<T>{v, v};
 }
-__device__ __forceinline__ double flip_sign(double v, uint32_t bit) {
-  return __hiloint2double(__double2hiint(v) ^ (int)(bit << 31), __double2loint(v));
+// acc + a.x * u + a.y * ju  ==  acc + a * u  (complex) when ju = i*u
+template <typename T>
+__device__ __forceinline__ V2<T> cfma(V2<T> a, V2<T> u, V2<T> ju, V2<T> acc) {
+  acc = __builtin_elementwise_fma(bcast<T>(a.x), u, acc);
+  return __builtin_elementwise_fma(bcast<T>(a.y), ju, acc);
+}
+template <typename T>
+__device__ __forceinline__ V2<T> cmul2(V2<T> a, V2<T> u, V2<T> ju) {
+  return __builtin_elementwise_fma(bcast<T>(a.y), ju, bcast<T>(a.x) * u);
+}
+template <typename T>
+__device__ __forceinline__ V2<T> times_i(V2<T> a) {
+  return V2<T>{-a.y, a.x};
 }
 
 // ---------------------------------------------------------------------------
-// single-qubit gate on bit position Q of the amplitude index.
-// u = {u00r,u00i,u01r,u01i,u10r,u10i,u11r,u11i}; wave-uniform (SGPR) for the
-// shared Rot gates, per-lane for per-sample encodings.
+// cross-lane exchange: value held by lane (l ^ MASK), VALU only
 // ---------------------------------------------------------------------------
-template <typename T, int N, int Q>
-__device__ __forceinline__ void apply_gate(T (&re)[Layout<N>::R], T (&im)[Layout<N>::R],
-                                           const T (&u)[8], int lane) {
-  using L = Layout<N>;
-  if constexpr (Q >= L::LB) {
-    constexpr int J = 1 << (Q - L::LB);
-#pragma unroll
-    for (int r = 0; r < L::R; ++r) {
-      if ((r & J) == 0) {
-        const int r1 = r | J;
-        const T a0r = re[r], a0i = im[r], a1r = re[r1], a1i = im[r1];
-        re[r] = u[0] * a0r - u[1] * a0i + u[2] * a1r - u[3] * a1i;
-        im[r] = u[0] * a0i + u[1] * a0r + u[2] * a1i + u[3] * a1r;
-        re[r1] = u[4] * a0r - u[5] * a0i + u[6] * a1r - u[7] * a1i;
-        im[r1] = u[4] * a0i + u[5] * a0r + u[6] * a1i + u[7] * a1r;
-      }
-    }
+template <int MASK>
+__device__ __forceinline__ int xlane_i32(int v, int lane) {
+  if constexpr (MASK == 1) {
+    return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);  // quad_perm [1,0,3,2]
+  } else if constexpr (MASK == 2) {
+    return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
+  } else if constexpr (MASK == 4) {
+    const int t = __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);  // row_half_mirror: l ^ 7
+    return __builtin_amdgcn_mov_dpp(t, 0x1B, 0xF, 0xF, true);          // quad_perm [3,2,1,0]: ^ 3
+  } else if constexpr (MASK == 8) {
+    return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);  // row_ror:8
+  } else if constexpr (MASK == 16) {
+    // odd rows of the first operand <-> even rows of the second
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (lane & 16) ? (int)r[0] : (int)r[1];
   } else {
-    const bool hi = (lane >> Q) & 1;
-    const T car = hi ? u[6] : u[0], cai = hi ? u[7] : u[1];  // own amplitude: U11 | U00
-    const T cbr = hi ? u[4] : u[2], cbi = hi ? u[5] : u[3];  // partner:       U10 | U01
-#pragma unroll
-    for (int r = 0; r < L::R; ++r) {
-      const T ar = re[r], ai = im[r];
-      const T pr = xlane<(1 << Q)>(ar), pi = xlane<(1 << Q)>(ai);
-      re[r] = car * ar - cai * ai + cbr * pr - cbi * pi;
-      im[r] = car * ai + cai * ar + cbr * pi + cbi * pr;
-    }
+    static_assert(MASK == 32, "lane masks are single bits below 64");
+    // upper half of the first operand <-> lower half of the second
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (lane & 32) ? (int)r[0] : (int)r[1];
   }
 }
-
-// one Rot layer: gates (gate0 + w) on wire w, w = 0..N-1, matrices from the table
-template <typename T, int N, int W>
-__device__ __forceinline__ void rot_layer(T (&re)[Layout<N>::R], T (&im)[Layout<N>::R],
-                                          const T* __restrict__ table, int gate0, int shift_gate,
-                                          int shift_var, int lane) {
-  if constexpr (W < N) {
-    const int g = gate0 + W;
-    const int var = (g == shift_gate) ? shift_var : 0;
-    const T* __restrict__ up = table + ((size_t)g * kVariants + var) * kGateReals;
-    T u[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) u[i] = up[i];
-    apply_gate<T, N, N - 1 - W>(re, im, u, lane);
-    rot_layer<T, N, W + 1>(re, im, table, gate0, shift_gate, shift_var, lane);
-  }
+template <int MASK>
+__device__ __forceinline__ float xlane(float v, int lane) {
+  return __int_as_float(xlane_i32<MASK>(__float_as_int(v), lane));
+}
+template <int MASK>
+__device__ __forceinline__ double xlane(double v, int lane) {
+  const int lo = xlane_i32<MASK>(__double2loint(v), lane);
+  const int hi = xlane_i32<MASK>(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+template <int MASK, typename T>
+__device__ __forceinline__ V2<T> xlane2(V2<T> a, int lane) {
+  return V2<T>{xlane<MASK>(a.x, lane), xlane<MASK>(a.y, lane)};
 }
 
-// per-sample RY(x_w) layer (qml.AngleEmbedding rotation="Y")
-template <typename T, int N, int W>
-__device__ __forceinline__ void ry_layer(T (&re)[Layout<N>::R], T (&im)[Layout<N>::R],
-                                         const T (&xs)[N], int lane) {
-  if constexpr (W < N) {
-    T s, c;
-    qsincos(xs[W] * (T)0.5, &s, &c);
-    const T u[8] = {c, (T)0, -s, (T)0, s, (T)0, c, (T)0};
-    apply_gate<T, N, N - 1 - W>(re, im, u, lane);
-    ry_layer<T, N, W + 1>(re, im, xs, lane);
-  }
+// sum over the 2^LB lanes of a sample; every lane ends with the total
+template <typename T, int LB>
+__device__ __forceinline__ T group_sum(T v, int lane) {
+  if constexpr (LB > 0) v += xlane<1>(v, lane);
+  if constexpr (LB > 1) v += xlane<2>(v, lane);
+  if constexpr (LB > 2) v += xlane<4>(v, lane);
+  if constexpr (LB > 3) v += xlane<8>(v, lane);
+  if constexpr (LB > 4) v += xlane<16>(v, lane);
+  if constexpr (LB > 5) v += xlane<32>(v, lane);
+  return v;
+}
+
+__device__ __forceinline__ float flip_sign(float v, uint32_t signbit) {
+  return __int_as_float(__float_as_int(v) ^ (int)signbit);
+}
+__device__ __forceinline__ double flip_sign(double v, uint32_t signbit) {
+  return __hiloint2double(__double2hiint(v) ^ (int)signbit, __double2loint(v));
 }
 
 // ---------------------------------------------------------------------------
-// LDS tables (built once per block): CZ-ring sign bits and CNOT-ring GF(2) maps
+// GF(2) index maps of the entangler rings
 // ---------------------------------------------------------------------------
 template <int N>
 __device__ __forceinline__ uint32_t cnot_ring_map(uint32_t k, int rr) {
@@ -189,7 +178,6 @@ __device__ __forceinline__ uint32_t cnot_ring_map(uint32_t k, int rr) {
   }
   return k;
 }
-
 template <int N>
 __device__ __forceinline__ uint32_t cz_ring_parity(uint32_t k, int rr) {
   // sum_i b_i * b_{(i+rr) % N} mod 2  ==  parity(k & rotl_N(k, rr))
@@ -197,83 +185,363 @@ __device__ __forceinline__ uint32_t cz_ring_parity(uint32_t k, int rr) {
   return __popc(k & rot) & 1u;
 }
 
-template <typename T, int N>
+// ---------------------------------------------------------------------------
+// LDS carve-up
+// ---------------------------------------------------------------------------
+template <typename T, int N, int LBMAX = 6>
 struct Smem {
-  using L = Layout<N>;
-  static constexpr int kCz = L::NR * kWave;              // u32 [range][lane]
-  static constexpr int kCnLane = L::NR * kWave;          // u32 [range][lane]
-  static constexpr int kCnReg = L::NR * L::R;            // u32 [range][r]
-  static constexpr int kTableWords = kCz + kCnLane + kCnReg;
-  static constexpr size_t kTableBytes = ((size_t)kTableWords * 4 + 15) / 16 * 16;
+  using L = Layout<N, LBMAX>;
+  static constexpr int kCz = L::NR * kWave;      // u32 [range][lane]
+  static constexpr int kCnLane = L::NR * kWave;  // u32 [range][lane]
+  static constexpr int kCnReg = L::NR * L::R;    // u32 [range][r]
+  static constexpr size_t kTableBytes = ((size_t)(kCz + kCnLane + kCnReg) * 4 + 15) / 16 * 16;
   static constexpr size_t kScratchBytes = (size_t)kWavesPerBlock * kWave * L::R * 2 * sizeof(T);
-  static size_t bytes(bool cnot) { return kTableBytes + (cnot ? kScratchBytes : 0); }
+  __host__ __device__ static size_t gate_bytes(int64_t n_rot) { return (size_t)n_rot * kLdsGateReals * sizeof(T); }
+  __host__ __device__ static size_t bytes(int64_t n_rot, bool cnot) {
+    return gate_bytes(n_rot) + kTableBytes + (cnot ? kScratchBytes : 0);
+  }
 };
 
 // ---------------------------------------------------------------------------
-// the kernel
+// the engine: everything a wave needs to push its samples through the circuit
 // ---------------------------------------------------------------------------
-template <typename T, int N, bool SHIFT>
-__global__ __launch_bounds__(kBlock) void circuit_kernel(const KParams p) {
-  using L = Layout<N>;
-  using S = Smem<T, N>;
-  constexpr int LB = L::LB, R = L::R, LPS = L::LPS, SPW = L::SPW;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  uint32_t* s_cz = reinterpret_cast<uint32_t*>(smem_raw);
-  uint32_t* s_cn_lane = s_cz + S::kCz;
-  uint32_t* s_cn_reg = s_cn_lane + S::kCnLane;
-  C2<T>* s_scratch = reinterpret_cast<C2<T>*>(smem_raw + S::kTableBytes);
+template <typename T, int N, int LBMAX = 6>
+struct Engine {
+  using L = Layout<N, LBMAX>;
+  using S = Smem<T, N, LBMAX>;
+  using C = V2<T>;
+  static constexpr int LB = L::LB, R = L::R, LPS = L::LPS, SPW = L::SPW;
 
-  const int tid = threadIdx.x;
-  const int lane = tid & (kWave - 1);
-  const int wave = tid >> 6;
-  const int sub = lane & (LPS - 1);
-  const int swave = lane >> LB;  // sample slot inside the wave
-  const bool use_cnot = p.imprimitive == 0;
+  const T* s_gates;
+  const uint32_t* s_cz;
+  const uint32_t* s_cn_lane;
+  const uint32_t* s_cn_reg;
+  C* s_slab;  // this wave's sample slot in the CNOT scratch
+  int lane, sub;
 
-  if constexpr (N > 1) {
-    if (use_cnot) {
-      for (int i = tid; i < L::NR * kWave; i += kBlock) {
-        const int rr = i / kWave + 1;
-        s_cn_lane[i] = cnot_ring_map<N>((uint32_t)((i % kWave) & (LPS - 1)), rr);
-      }
-      for (int i = tid; i < L::NR * R; i += kBlock) {
-        const int rr = i / R + 1;
-        s_cn_reg[i] = cnot_ring_map<N>((uint32_t)(i % R) << LB, rr);
-      }
-    } else {
-      for (int i = tid; i < L::NR * kWave; i += kBlock) {
-        const int rr = i / kWave + 1;
-        const uint32_t ls = (uint32_t)((i % kWave) & (LPS - 1));
-        uint32_t bits = 0;
+  struct Shift {
+    int blk = -1, wire = 0;  // shifted input-angle occurrence (block, wire)
+    T sign = 0;
+  };
+
+  // -- block-level staging (all threads of the block; ends with a barrier) -------------
+  __device__ __forceinline__ void stage(unsigned char* smem, const T* __restrict__ table, int n_rot,
+                                        bool use_cnot, int shift_gate, int shift_var) {
+    T* gates = reinterpret_cast<T*>(smem);
+    uint32_t* cz = reinterpret_cast<uint32_t*>(smem + S::gate_bytes(n_rot));
+    uint32_t* cn_lane = cz + S::kCz;
+    uint32_t* cn_reg = cn_lane + S::kCnLane;
+    const int tid = threadIdx.x;
+    for (int g = tid; g < n_rot; g += kBlock) {
+      const int var = (g == shift_gate) ? shift_var : 0;
+      const T* u = table + ((size_t)g * kVariants + var) * kGateReals;
+      T* d = gates + (size_t)g * kLdsGateReals;
+      const T u00r = u[0], u00i = u[1], u01r = u[2], u01i = u[3];
+      const T u10r = u[4], u10i = u[5], u11r = u[6], u11i = u[7];
+      d[0] = u00r;  d[1] = u00i;  d[2] = -u00i;  d[3] = u00r;    // u00, i*u00
+      d[4] = u01r;  d[5] = u01i;  d[6] = -u01i;  d[7] = u01r;    // u01, i*u01
+      d[8] = u11r;  d[9] = u11i;  d[10] = -u11i; d[11] = u11r;   // u11, i*u11
+      d[12] = u10r; d[13] = u10i; d[14] = -u10i; d[15] = u10r;   // u10, i*u10
+    }
+    if constexpr (N > 1) {
+      if (use_cnot) {
+        for (int i = tid; i < L::NR * kWave; i += kBlock)
+          cn_lane[i] = cnot_ring_map<N>((uint32_t)((i % kWave) & (LPS - 1)), i / kWave + 1);
+        for (int i = tid; i < L::NR * R; i += kBlock)
+          cn_reg[i] = cnot_ring_map<N>((uint32_t)(i % R) << LB, i / R + 1);
+      } else {
+        for (int i = tid; i < L::NR * kWave; i += kBlock) {
+          const uint32_t ls = (uint32_t)((i % kWave) & (LPS - 1));
+          uint32_t bits = 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) bits |= cz_ring_parity<N>(((uint32_t)r << LB) | ls, rr) << r;
-        s_cz[i] = bits;
+          for (int r = 0; r < R; ++r)
+            bits |= cz_ring_parity<N>(((uint32_t)r << LB) | ls, i / kWave + 1) << r;
+          cz[i] = bits;
+        }
+      }
+    }
+    __syncthreads();
+    s_gates = gates;
+    s_cz = cz;
+    s_cn_lane = cn_lane;
+    s_cn_reg = cn_reg;
+    lane = tid & (kWave - 1);
+    sub = lane & (LPS - 1);
+    const int wave = tid >> 6;
+    s_slab = reinterpret_cast<C*>(smem + S::gate_bytes(n_rot) + S::kTableBytes) +
+             (size_t)(wave * SPW + (lane >> LB)) * L::D;
+  }
+
+  // -- single-qubit gate on bit Q; matrix halves lo = [u00,iu00,u01,iu01], hi = [u11,iu11,u10,iu10]
+  template <int Q>
+  __device__ __forceinline__ void gate_regs(C (&a)[R], const C (&lo)[4], const C (&hi)[4]) const {
+    constexpr int J = 1 << (Q - LB);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if ((r & J) == 0) {
+        const C a0 = a[r], a1 = a[r | J];
+        a[r] = cfma<T>(a1, lo[2], lo[3], cmul2<T>(a0, lo[0], lo[1]));
+        a[r | J] = cfma<T>(a0, hi[2], hi[3], cmul2<T>(a1, hi[0], hi[1]));
       }
     }
   }
-  __syncthreads();
+  template <int Q>
+  __device__ __forceinline__ void gate_lane(C (&a)[R], const C (&h)[4]) const {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const C own = a[r];
+      const C par = xlane2<(1 << Q), T>(own, lane);
+      a[r] = cfma<T>(par, h[2], h[3], cmul2<T>(own, h[0], h[1]));
+    }
+  }
 
-  const T* __restrict__ table = static_cast<const T*>(p.table);
-  const T* __restrict__ inputs = static_cast<const T*>(p.inputs);
-  const int n_rot_total = p.n_rounds * p.n_blocks * p.sel_layers * N;
+  // -- one Rot layer from the LDS gate table ------------------------------------------
+  template <int W>
+  __device__ __forceinline__ void rot_layer(C (&a)[R], int gate0) const {
+    if constexpr (W < N) {
+      constexpr int Q = N - 1 - W;
+      const C* gp = reinterpret_cast<const C*>(s_gates + (size_t)(gate0 + W) * kLdsGateReals);
+      if constexpr (Q >= LB) {
+        C lo[4], hi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          lo[i] = gp[i];
+          hi[i] = gp[4 + i];
+        }
+        gate_regs<Q>(a, lo, hi);
+      } else {
+        const C* hp = gp + (((lane >> Q) & 1) << 2);
+        C h[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = hp[i];
+        gate_lane<Q>(a, h);
+      }
+      rot_layer<W + 1>(a, gate0);
+    }
+  }
 
-  // parameter-shift replica (wave-uniform)
-  int shift_gate = -1, shift_var = 0, shift_blk = -1, shift_wire = 0;
-  T shift_sign = 0;
-  int replica_local = 0;
+  // -- per-sample RY(x_w) layer (qml.AngleEmbedding rotation="Y") -----------------------
+  template <int W>
+  __device__ __forceinline__ void ry_layer(C (&a)[R], const T (&cs)[N], const T (&sn)[N]) const {
+    if constexpr (W < N) {
+      constexpr int Q = N - 1 - W;
+      const T c = cs[W], s = sn[W], z = 0;
+      if constexpr (Q >= LB) {
+        const C lo[4] = {C{c, z}, C{z, c}, C{-s, z}, C{z, -s}};
+        const C hi[4] = {C{c, z}, C{z, c}, C{s, z}, C{z, s}};
+        gate_regs<Q>(a, lo, hi);
+      } else {
+        const T sp = ((lane >> Q) & 1) ? s : -s;
+        const C h[4] = {C{c, z}, C{z, c}, C{sp, z}, C{z, sp}};
+        gate_lane<Q>(a, h);
+      }
+      ry_layer<W + 1>(a, cs, sn);
+    }
+  }
+
+  // -- entangler ring of range index ri (range = ri + 1) --------------------------------
+  __device__ __forceinline__ void ring(C (&a)[R], int ri, bool use_cnot) const {
+    if constexpr (N > 1) {
+      if (!use_cnot) {
+        const uint32_t bits = s_cz[ri * kWave + lane];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint32_t sb = ((bits >> r) & 1u) << 31;
+          a[r] = C{flip_sign(a[r].x, sb), flip_sign(a[r].y, sb)};
+        }
+      } else {
+        const uint32_t lane_term = s_cn_lane[ri * kWave + lane];
+#pragma unroll
+        for (int r = 0; r < R; ++r) s_slab[lane_term ^ s_cn_reg[ri * R + r]] = a[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[r] = s_slab[(r << LB) | sub];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+  }
+
+  // -- cos/sin of every half input angle; all lanes of the sample end up holding all N ----
+  __device__ __forceinline__ void half_angle_sincos(const T (&xs)[N], T (&cs)[N], T (&sn)[N]) const {
+    if constexpr (LPS >= N) {
+      // lane j of the sample evaluates wire j, then the N results are gathered
+      // arithmetic select: a ?: chain over xs[] is turned into a scratch-indexed load by LLVM
+      T mine = 0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) mine = fma((T)(sub == j ? 1 : 0), xs[j], mine);
+      T s, c;
+      qsincos(mine * (T)0.5, &s, &c);
+      const int base = lane & ~(LPS - 1);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        cs[j] = __shfl(c, base | j, kWave);
+        sn[j] = __shfl(s, base | j, kWave);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; ++j) qsincos(xs[j] * (T)0.5, &sn[j], &cs[j]);
+    }
+  }
+
+  // -- RZ-encoding diagonal prod_j exp(-+ i x_j / 2) for this lane's R amplitudes ----------
+  __device__ __forceinline__ void rz_diagonal(const T (&cs)[N], const T (&sn)[N], C (&dx)[R]) const {
+    T accr = 1, acci = 0;
+#pragma unroll
+    for (int q = 0; q < LB; ++q) {  // lane bits: wire N-1-q
+      const T c = cs[N - 1 - q];
+      const T si = ((lane >> q) & 1) ? sn[N - 1 - q] : -sn[N - 1 - q];
+      const T nr = accr * c - acci * si;
+      acci = accr * si + acci * c;
+      accr = nr;
+    }
+    dx[0] = C{accr, acci};
+#pragma unroll
+    for (int j = 0; j < N - LB; ++j) {  // register bits: wire N-1-(LB+j)
+      const T c = cs[N - 1 - (LB + j)], s = sn[N - 1 - (LB + j)];
+#pragma unroll
+      for (int r = 0; r < (1 << j); ++r) {
+        const C d = dx[r];
+        dx[r | (1 << j)] = C{d.x * c - d.y * s, d.x * s + d.y * c};  // bit set:   * (c + i s)
+        dx[r] = C{d.x * c + d.y * s, d.y * c - d.x * s};             // bit clear: * (c - i s)
+      }
+    }
+  }
+
+  // -- all rounds of the circuit for this wave's sample(s) --------------------------------
+  // xs: input angles (already scaled) for RZ/RY encodings; amp_row: feature row for
+  // amplitude embedding.  On return pr[] holds the probabilities of this lane's
+  // amplitudes and, for the <Z> read-out, result[] the n expectation values.
+  __device__ __forceinline__ void run(const KScalars& p, const T* __restrict__ amp_row, T (&xs)[N],
+                                      const Shift& sh, T (&result)[N], T (&pr)[R]) const {
+    const bool use_cnot = p.imprimitive == 0;
+    C a[R];
+    C dx[R];
+    T cs[N], sn[N];
+    for (int round = 0; round < p.n_rounds; ++round) {
+      // ---- state preparation ---------------------------------------------------------
+      if (p.encoding == 1) {
+        T n2 = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const int k = (r << LB) | sub;
+          T v = (T)p.pad_with;
+          if (k < p.n_features) v = amp_row[k] + (T)p.enc_offset;
+          a[r] = C{v, (T)0};
+          n2 += v * v;
+        }
+        n2 = group_sum<T, LB>(n2, lane);
+        const T inv = (T)1 / qsqrt(n2);
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[r] = C{a[r].x * inv, (T)0};
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[r] = C{(T)0, (T)0};
+        a[0] = C{sub == 0 ? (T)1 : (T)0, (T)0};
+      }
+      if (p.encoding == 2 || p.encoding == 3) half_angle_sincos(xs, cs, sn);
+      if (p.encoding == 2) rz_diagonal(cs, sn, dx);
+
+      // ---- blocks -----------------------------------------------------------------------
+      for (int blk = 0; blk < p.n_blocks; ++blk) {
+        if (p.encoding == 2) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) a[r] = cmul2<T>(dx[r], a[r], times_i<T>(a[r]));
+          if (blk == sh.blk) {  // parameter shift: extra RZ(+-pi/2) on sh.wire
+            const int q = N - 1 - sh.wire;
+            const T h = (T)0.70710678118654752440;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const int k = (r << LB) | sub;
+              const T si = ((k >> q) & 1) ? h * sh.sign : -h * sh.sign;
+              a[r] = C{a[r].x * h - a[r].y * si, a[r].x * si + a[r].y * h};
+            }
+          }
+        } else if (p.encoding == 3 && blk == 0) {
+          if (sh.blk == 0) {  // parameter shift of one RY input angle: rotate (c, s) by +-pi/4
+            const T h = (T)0.70710678118654752440;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+              if (j == sh.wire) {
+                const T c = cs[j], s = sn[j];
+                cs[j] = h * (c - sh.sign * s);
+                sn[j] = h * (s + sh.sign * c);
+              }
+            }
+          }
+          ry_layer<0>(a, cs, sn);
+        }
+        for (int s = 0; s < p.sel_layers; ++s) {
+          rot_layer<0>(a, ((round * p.n_blocks + blk) * p.sel_layers + s) * N);
+          if constexpr (N > 1) ring(a, s % (N - 1), use_cnot);
+        }
+      }
+
+      // ---- measurement -------------------------------------------------------------------
+#pragma unroll
+      for (int r = 0; r < R; ++r) pr[r] = a[r].x * a[r].x + a[r].y * a[r].y;
+      if (p.measure == 1) {
+#pragma unroll
+        for (int w = 0; w < N; ++w) {
+          const int q = N - 1 - w;
+          T acc = 0;
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc += ((((r << LB) | sub) >> q) & 1) ? -pr[r] : pr[r];
+          result[w] = group_sum<T, LB>(acc, lane);
+        }
+      }
+      // ---- chain into the next round: x <- out[:, 0:N] ------------------------------------
+      if (round + 1 < p.n_rounds) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const T v = (p.measure == 1)
+                          ? result[j]
+                          : __shfl(pr[0], (lane & ~(LPS - 1)) | (j & (LPS - 1)), kWave);
+          xs[j] = v * (T)p.enc_scale;
+        }
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// circuit kernel: inputs -> probabilities / <Z>   (SHIFT: -> dot with upstream grad)
+// ---------------------------------------------------------------------------
+template <typename T, int N, bool SHIFT>
+__global__ __launch_bounds__(kBlock) void circuit_kernel(const T* __restrict__ inputs,
+                                                         const T* __restrict__ table,
+                                                         T* __restrict__ out,
+                                                         const T* __restrict__ gout,
+                                                         T* __restrict__ dots, const KScalars p) {
+  using E = Engine<T, N>;
+  using L = typename E::L;
+  constexpr int LB = L::LB, R = L::R, SPW = L::SPW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int n_rot = p.n_rounds * p.n_blocks * p.sel_layers * N;
+  int shift_gate = -1, shift_var = 0, replica_local = 0;
+  typename E::Shift sh;
   if constexpr (SHIFT) {
     replica_local = blockIdx.y;
     const int rho = p.first_replica + replica_local;
-    if (rho < 6 * n_rot_total) {
+    if (rho < 6 * n_rot) {
       shift_gate = rho / 6;
       shift_var = 1 + rho % 6;
     } else {
-      const int q = rho - 6 * n_rot_total;
-      shift_blk = q / (2 * N);
-      shift_wire = (q >> 1) % N;
-      shift_sign = (q & 1) ? (T)-1 : (T)1;
+      const int q = rho - 6 * n_rot;
+      sh.blk = q / (2 * N);
+      sh.wire = (q >> 1) % N;
+      sh.sign = (q & 1) ? (T)-1 : (T)1;
     }
   }
+  E eng;
+  eng.stage(smem_raw, table, n_rot, p.imprimitive == 0, shift_gate, shift_var);
+  const int lane = eng.lane, sub = eng.sub;
+  const int wave = threadIdx.x >> 6;
+  const int swave = lane >> LB;
 
   const int64_t groups = (p.batch + SPW - 1) / SPW;
   for (int64_t grp = (int64_t)blockIdx.x * kWavesPerBlock + wave; grp < groups;
@@ -282,11 +550,7 @@ __global__ __launch_bounds__(kBlock) void circuit_kernel(const KParams p) {
     const bool valid = sample_raw < p.batch;
     const int64_t sample = valid ? sample_raw : p.batch - 1;
 
-    T re[R], im[R];
     T xs[N];
-    T dxr[R], dxi[R];  // per-sample diagonal of the RZ encoding layer
-
-    // ---- round-0 inputs ----------------------------------------------------
     if (p.encoding == 2 || p.encoding == 3) {
 #pragma unroll
       for (int j = 0; j < N; ++j) xs[j] = inputs[sample * p.in_ld + j] * (T)p.enc_scale;
@@ -294,191 +558,27 @@ __global__ __launch_bounds__(kBlock) void circuit_kernel(const KParams p) {
 #pragma unroll
       for (int j = 0; j < N; ++j) xs[j] = (T)0;
     }
+    T result[N], pr[R];
+    eng.run(p, inputs + sample * p.in_ld, xs, sh, result, pr);
 
-    T result[N];  // <Z_i> of the last round (expz)
-    T pr[R];      // probabilities of the last round (probs)
-
-    for (int round = 0; round < p.n_rounds; ++round) {
-      // ---- state preparation -------------------------------------------------
-      if (p.encoding == 1) {
-        T n2 = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const int k = (r << LB) | sub;
-          T v = (T)p.pad_with;
-          if (k < p.n_features) v = inputs[sample * p.in_ld + k] + (T)p.enc_offset;
-          re[r] = v;
-          im[r] = 0;
-          n2 += v * v;
-        }
-        n2 = group_sum<T, LB>(n2);
-        const T inv = (T)1 / qsqrt(n2);
-#pragma unroll
-        for (int r = 0; r < R; ++r) re[r] *= inv;
-      } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          re[r] = 0;
-          im[r] = 0;
-        }
-        re[0] = sub == 0 ? (T)1 : (T)0;
-      }
-
-      // ---- per-sample RZ-encoding diagonal: prod_j exp(-+ i x_j / 2) ---------
-      if (p.encoding == 2) {
-        T accr = 1, acci = 0;
-#pragma unroll
-        for (int q = 0; q < LB; ++q) {  // lane bits: wires N-1-q
-          T s, c;
-          qsincos(xs[N - 1 - q] * (T)0.5, &s, &c);
-          const T si = ((lane >> q) & 1) ? s : -s;
-          const T nr = accr * c - acci * si;
-          acci = accr * si + acci * c;
-          accr = nr;
-        }
-        dxr[0] = accr;
-        dxi[0] = acci;
-#pragma unroll
-        for (int j = 0; j < N - LB; ++j) {  // register bits: wires N-1-(LB+j)
-          T s, c;
-          qsincos(xs[N - 1 - (LB + j)] * (T)0.5, &s, &c);
-#pragma unroll
-          for (int r = 0; r < (1 << j); ++r) {
-            const T ar = dxr[r], ai = dxi[r];
-            dxr[r | (1 << j)] = ar * c - ai * s;   // bit set:   * (c + i s)
-            dxi[r | (1 << j)] = ar * s + ai * c;
-            dxr[r] = ar * c + ai * s;              // bit clear: * (c - i s)
-            dxi[r] = ai * c - ar * s;
-          }
-        }
-      }
-
-      // ---- blocks ----------------------------------------------------------------
-      for (int blk = 0; blk < p.n_blocks; ++blk) {
-        if (p.encoding == 2) {
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const T ar = re[r], ai = im[r];
-            re[r] = ar * dxr[r] - ai * dxi[r];
-            im[r] = ar * dxi[r] + ai * dxr[r];
-          }
-          if constexpr (SHIFT) {
-            if (blk == shift_blk) {  // extra RZ(+-pi/2) on shift_wire
-              const int q = N - 1 - shift_wire;
-              const T h = (T)0.70710678118654752440;
-#pragma unroll
-              for (int r = 0; r < R; ++r) {
-                const int k = (r << LB) | sub;
-                const T si = ((k >> q) & 1) ? h * shift_sign : -h * shift_sign;
-                const T ar = re[r], ai = im[r];
-                re[r] = ar * h - ai * si;
-                im[r] = ar * si + ai * h;
-              }
-            }
-          }
-        } else if (p.encoding == 3 && blk == 0) {
-          if constexpr (SHIFT) {
-            if (shift_blk == 0) {
-#pragma unroll
-              for (int j = 0; j < N; ++j)
-                if (j == shift_wire) xs[j] += shift_sign * (T)1.57079632679489661923;
-            }
-          }
-          ry_layer<T, N, 0>(re, im, xs, lane);
-        }
-
-        for (int s = 0; s < p.sel_layers; ++s) {
-          const int gate0 = ((round * p.n_blocks + blk) * p.sel_layers + s) * N;
-          rot_layer<T, N, 0>(re, im, table, gate0, shift_gate, shift_var, lane);
-          if constexpr (N > 1) {
-            const int ri = s % (N - 1);  // range index (range = ri + 1)
-            if (!use_cnot) {
-              const uint32_t bits = s_cz[ri * kWave + lane];
-#pragma unroll
-              for (int r = 0; r < R; ++r) {
-                const uint32_t b = (bits >> r) & 1u;
-                re[r] = flip_sign(re[r], b);
-                im[r] = flip_sign(im[r], b);
-              }
-            } else {
-              C2<T>* slab = s_scratch + (size_t)(wave * SPW + swave) * L::D;
-              const uint32_t lane_term = s_cn_lane[ri * kWave + lane];
-#pragma unroll
-              for (int r = 0; r < R; ++r) {
-                const uint32_t dst = lane_term ^ s_cn_reg[ri * R + r];
-                slab[dst] = C2<T>{re[r], im[r]};
-              }
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-              for (int r = 0; r < R; ++r) {
-                const int k = (r << LB) | sub;
-                const C2<T> a = slab[k];
-                re[r] = a.x;
-                im[r] = a.y;
-              }
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-              __builtin_amdgcn_wave_barrier();
-              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-          }
-        }
-      }
-
-      // ---- measurement -------------------------------------------------------------
-#pragma unroll
-      for (int r = 0; r < R; ++r) pr[r] = re[r] * re[r] + im[r] * im[r];
-      if (p.measure == 1) {
-#pragma unroll
-        for (int w = 0; w < N; ++w) {
-          const int q = N - 1 - w;
-          T acc = 0;
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const int k = (r << LB) | sub;
-            acc += ((k >> q) & 1) ? -pr[r] : pr[r];
-          }
-          result[w] = group_sum<T, LB>(acc);
-        }
-      }
-      // ---- chain into the next round: x <- out[:, 0:N] ----------------------------
-      if (round + 1 < p.n_rounds) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-          T v;
-          if (p.measure == 1) {
-            v = result[j];
-          } else {
-            v = __shfl(pr[0], (lane & ~(LPS - 1)) | (j & (LPS - 1)), 64);
-          }
-          xs[j] = v * (T)p.enc_scale;
-        }
-      }
-    }
-
-    // ---- epilogue --------------------------------------------------------------------
     if constexpr (!SHIFT) {
-      T* __restrict__ out = static_cast<T*>(p.out);
       if (p.measure == 0) {
         if (valid) {
 #pragma unroll
           for (int r = 0; r < R; ++r) out[sample * p.out_ld + ((r << LB) | sub)] = pr[r];
         }
       } else {
-        T v = result[0];
+        T v = 0;  // arithmetic select (see half_angle_sincos)
 #pragma unroll
-        for (int w = 1; w < N; ++w) v = (sub == w) ? result[w] : v;
+        for (int w = 0; w < N; ++w) v = fma((T)(sub == w ? 1 : 0), result[w], v);
         if (valid && sub < N) out[sample * p.out_ld + sub] = v;
       }
     } else {
-      const T* __restrict__ gout = static_cast<const T*>(p.gout);
-      T* __restrict__ dots = static_cast<T*>(p.dots);
       T acc = 0;
       if (p.measure == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r) acc += gout[sample * p.g_ld + ((r << LB) | sub)] * pr[r];
-        acc = group_sum<T, LB>(acc);
+        acc = group_sum<T, LB>(acc, lane);
       } else {
 #pragma unroll
         for (int w = 0; w < N; ++w) acc += gout[sample * p.g_ld + w] * result[w];
