@@ -9,7 +9,8 @@ samples are independent): BASELINE configs[1] = MNIST 28x2
 qdense ``QNN_noise(784, 8, 14)`` (reference default model, src/mnist_exm.py:48), batch 256 per
 GPU.  One step = one body of ``Diffusion.sample`` (reference src/models.py:127-134):
 ``x <- net(x)`` on a resident (256, 1, 28, 28) float64 batch, i.e.
-linear_down -> [RZ encoders + 14 x (8 Rot + 8 CZ) + <Z>] -> linear_up.  Synthetic
+linear_down -> [RZ encoders + 14 x (8 Rot + 8 CZ) + <Z>] -> linear_up, one fused launch
+(qiddm_dense_forward).  Synthetic
 random-noise images (``rand*0.75+0.5``, src/mnist_exm.py:396), random-init weights under
 ``torch.manual_seed(42)``.  The step is captured once into a hipGraph and replayed.
 
@@ -93,26 +94,28 @@ def make_step(diff, x0, use_graph):
     return graph.replay, x
 
 
-def time_circuit_kernel(net, batch, dev, launches=200):
-    """Average duration of the dominant kernel (circuit_kernel<float, 8>) measured with HIP
-    events on the stream it is launched on: `launches` back-to-back launches inside one
-    hipGraph replay, same arguments as in the timed step."""
-    from qiddm_amd.circuit import Circuit, prepare_gates, run_forward
-    circ = Circuit(n_qubits=N_QUBITS, encoding="rz", imprimitive="CZ", measure="expz", sel_layers=QDEPTH)
-    angles = net.weights.detach().reshape(circ.angles_shape)
-    x = torch.randn(batch, N_QUBITS, device=dev)
-    table = prepare_gates(circ, angles, "f32")
-    out = run_forward(circ, x, angles, "f32", table=table)
+def time_dominant_kernel(net, x_dev, launches=200):
+    """Average duration of the dominant kernel (dense_forward_kernel<float, 8>: linear_down +
+    circuit + linear_up of one denoise step) measured with HIP events on the stream it is launched
+    on: `launches` back-to-back launches inside one hipGraph replay, same arguments as in the
+    timed step."""
+    circ = net._circuit_descriptor()
+
+    def once():
+        with torch.no_grad():
+            return net(x_dev)
+
+    once()
     torch.cuda.synchronize()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        run_forward(circ, x, angles, "f32", table=table)
+        once()
     torch.cuda.current_stream().wait_stream(side)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for _ in range(launches):
-            out = run_forward(circ, x, angles, "f32", table=table)
+            once()
     g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -199,7 +202,7 @@ def main():
     value = images / elapsed
     result = None
     if rank == 0:
-        kern_us, circ = time_circuit_kernel(diff.net, args.batch, dev)
+        kern_us, circ = time_dominant_kernel(diff.net, x0.to(dev))
         g_per_sample = circ.gate_count()
         alg_bytes = circ.algorithmic_bytes_per_sample("f32") * args.batch      # per launch
         achieved = alg_bytes / (kern_us * 1e-6) / 1e9
@@ -225,12 +228,13 @@ def main():
             "gate_apps_per_s": value * g_per_sample,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_pmc_traffic("circuit_kernel", args.batch),
-                         "kernel": "qiddm::circuit_kernel<float, 8, false>",
+                         "traffic": load_pmc_traffic("dense_forward_kernel<float, 8>", args.batch),
+                         "kernel": "qiddm::dense_forward_kernel<float, 8>",
                          "kernel_avg_us": kern_us,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "algorithmic = (G+1/2)*16*2^n B per sample (SURVEY 8d); the slab lives "
-                                 "in registers, so physical HBM traffic is inputs+outputs only"},
+                         "note": "algorithmic = (G+1/2)*16*2^n B per sample (SURVEY 8d) x batch; the slab "
+                                 "lives in registers, so physical HBM traffic is images in/out + weights; "
+                                 "the kernel also does linear_down/linear_up of the step"},
         }
         if not args.no_cpu_baseline and world == 1:
             v, n_steps, el = cpu_baseline(diff, x0, args.cpu_seconds)

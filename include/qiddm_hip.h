@@ -149,6 +149,27 @@ int qiddm_forward_shifted(const qiddm_circuit_t *circ, const void *inputs, int64
                           int64_t g_ld, int64_t first_replica, int64_t n_replicas, void *dots,
                           void *stream);
 
+/* ---- fused dense-net forward ------------------------------------------------------
+ * Replaces the whole forward of the reference's linear_down -> quantum rounds -> linear_up
+ * nets in one launch: QNN_noise.forward / QNN.forward (reference nn/qdense.py:267-289,
+ * 346-368) and QIDDM_LL_noise.forward (:1620-1642), i.e.
+ *     h   = x @ w_down^T + b_down                      (batch, n)        float64
+ *     ev  = circuit(h)  (circ: QIDDM_ENC_RZ, QIDDM_MEAS_EXPZ, any n_rounds/n_blocks/sel_layers)
+ *     net = ev @ w_up^T + b_up                         (batch, out_features)  float64
+ * and, with post_mode = 1, the "noise"-goal update of the sampling loop on top of it
+ * (reference src/models.py:130-134):  y = clamp(x - (net - 0.5) * 0.1 * noise_factor, 0, 1)
+ * (post_mode = 0: y = net).  The classical glue runs in float64 as in the reference, the
+ * statevector in circ->dtype.  `angles` is the raw (n_rounds, n_blocks, sel_layers, n, 3)
+ * float64 weight tensor: the Rot matrices are built inside the launch (no gate table).
+ * w_down: (n, in_features) row-major, w_up: (out_features, n) row-major (torch.nn.Linear
+ * layout); b_down / b_up may be NULL.  y must not alias x.  post_mode = 1 needs
+ * out_features == in_features.                                                           */
+int qiddm_dense_forward(const qiddm_circuit_t *circ, const double *x, int64_t batch, int64_t x_ld,
+                        int64_t in_features, const double *w_down, const double *b_down,
+                        const double *angles, const double *w_up, const double *b_up,
+                        int64_t out_features, int32_t post_mode, double noise_factor, double *y,
+                        int64_t y_ld, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,7 @@ EXPORTS = (
     "qiddm_prepare_gates",
     "qiddm_forward",
     "qiddm_forward_shifted",
+    "qiddm_dense_forward",
 )
 
 
@@ -89,6 +90,9 @@ def _declare(lib):
     lib.qiddm_forward.argtypes = [P, vp, i64, i64, vp, vp, i64, vp]
     lib.qiddm_forward_shifted.restype = ctypes.c_int
     lib.qiddm_forward_shifted.argtypes = [P, vp, i64, i64, vp, vp, i64, i64, i64, vp, vp]
+    lib.qiddm_dense_forward.restype = ctypes.c_int
+    lib.qiddm_dense_forward.argtypes = [P, vp, i64, i64, i64, vp, vp, vp, vp, vp, i64, ctypes.c_int32,
+                                        ctypes.c_double, vp, i64, vp]
 
 
 def _preload_torch_hip_runtime():

@@ -176,6 +176,39 @@ def run_forward(circ: Circuit, inputs, angles: torch.Tensor, precision: str | No
     return out
 
 
+def _as_f64(t, device):
+    return None if t is None else t.detach().to(device=device, dtype=torch.float64).contiguous()
+
+
+def dense_forward(circ: Circuit, x: torch.Tensor, w_down, b_down, angles, w_up, b_up,
+                  precision: str | None = None, post_mode: int = 0, noise_factor: float = 1.0):
+    """linear_down -> chained circuit rounds -> linear_up (+ optional sampling update) in ONE
+    launch (``qiddm_dense_forward``).  No autograd: inference / sampling path.
+    x: (batch, in_features) -> (batch, out_features) float64."""
+    precision = precision or _default_precision
+    _require_device(angles, "the circuit weights")
+    _require_device(x, "the input batch")
+    device = angles.device
+    if circ.encoding != "rz" or circ.measure != "expz":
+        raise ValueError("dense_forward needs encoding='rz' and measure='expz'")
+    if tuple(angles.shape) != circ.angles_shape:
+        raise ValueError(f"angles must have shape {circ.angles_shape}; got {tuple(angles.shape)}")
+    n = circ.n_qubits
+    xx = _as_f64(x, device)
+    wd, bd, wu, bu, ang = (_as_f64(t, device) for t in (w_down, b_down, w_up, b_up, angles))
+    if wd.shape != (n, xx.shape[1]) or wu.shape[1] != n:
+        raise ValueError(f"linear shapes {tuple(wd.shape)} / {tuple(wu.shape)} do not match n={n}, "
+                         f"in_features={xx.shape[1]}")
+    y = torch.empty(xx.shape[0], wu.shape[0], dtype=torch.float64, device=device)
+    cs = circ.c_struct(precision)
+    _capi.check(_capi.lib().qiddm_dense_forward(
+        ctypes.byref(cs), xx.data_ptr(), xx.shape[0], xx.stride(0), xx.shape[1], wd.data_ptr(),
+        0 if bd is None else bd.data_ptr(), ang.data_ptr(), wu.data_ptr(),
+        0 if bu is None else bu.data_ptr(), wu.shape[0], int(post_mode), float(noise_factor),
+        y.data_ptr(), y.stride(0), _stream_ptr(device)))
+    return y
+
+
 def run_shift_sweep(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch.Tensor,
                     precision: str | None = None, with_inputs: bool = True,
                     max_dots_elems: int = 1 << 26):

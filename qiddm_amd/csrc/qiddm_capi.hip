@@ -123,6 +123,57 @@ int dispatch_n(int n, const Ptrs& ptr, const qiddm::KScalars& p, int64_t n_repli
   }
 }
 
+template <typename T, int N>
+int launch_dense(const double* x, const double* wd, const double* bd, const double* angles,
+                 const double* wu, const double* bu, double* y, const qiddm::DenseScalars& d,
+                 const qiddm::KScalars& p, hipStream_t stream) {
+  using L = qiddm::Layout<N>;
+  using S = qiddm::Smem<T, N>;
+  const int64_t groups = (p.batch + L::SPW - 1) / L::SPW;
+  if (groups == 0) return QIDDM_OK;
+  int64_t bx = (groups + qiddm::kWavesPerBlock - 1) / qiddm::kWavesPerBlock;
+  if (bx > 4096) bx = 4096;
+  const int64_t n_rot = (int64_t)p.n_rounds * p.n_blocks * p.sel_layers * N;
+  const size_t smem = S::bytes(n_rot, p.imprimitive == QIDDM_IMP_CNOT);
+  if (smem > kMaxLds)
+    return fail(QIDDM_ERR_UNSUPPORTED, "circuit with %lld Rot gates needs %zu B of LDS (limit %zu)",
+                (long long)n_rot, smem, kMaxLds);
+  auto kern = qiddm::dense_forward_kernel<T, N>;
+  static bool big_lds_enabled = false;
+  if (smem > 48 * 1024 && !big_lds_enabled) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    if (ea != hipSuccess)
+      return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
+    big_lds_enabled = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)bx), dim3(qiddm::kBlock), smem, stream, x, wd, bd, angles, wu,
+                     bu, y, d, p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return fail(QIDDM_ERR_LAUNCH, "dense_forward_kernel<n=%d> launch failed: %s", N, hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
+template <typename T>
+int dispatch_dense(int n, const double* x, const double* wd, const double* bd, const double* angles,
+                   const double* wu, const double* bu, double* y, const qiddm::DenseScalars& d,
+                   const qiddm::KScalars& p, hipStream_t st) {
+  switch (n) {
+    case 1: return launch_dense<T, 1>(x, wd, bd, angles, wu, bu, y, d, p, st);
+    case 2: return launch_dense<T, 2>(x, wd, bd, angles, wu, bu, y, d, p, st);
+    case 3: return launch_dense<T, 3>(x, wd, bd, angles, wu, bu, y, d, p, st);
+    case 4: return launch_dense<T, 4>(x, wd, bd, angles, wu, bu, y, d, p, st);
+    case 5: return launch_dense<T, 5>(x, wd, bd, angles, wu, bu, y, d, p, st);
+    case 6: return launch_dense<T, 6>(x, wd, bd, angles, wu, bu, y, d, p, st);
+    case 7: return launch_dense<T, 7>(x, wd, bd, angles, wu, bu, y, d, p, st);
+    case 8: return launch_dense<T, 8>(x, wd, bd, angles, wu, bu, y, d, p, st);
+    case 9: return launch_dense<T, 9>(x, wd, bd, angles, wu, bu, y, d, p, st);
+    case 10: return launch_dense<T, 10>(x, wd, bd, angles, wu, bu, y, d, p, st);
+    default: return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d not instantiated", n);
+  }
+}
+
 qiddm::KScalars make_params(const qiddm_circuit_t* c) {
   qiddm::KScalars p;
   std::memset(&p, 0, sizeof(p));
@@ -270,6 +321,44 @@ int qiddm_forward_shifted(const qiddm_circuit_t* c, const void* inputs, int64_t 
   hipStream_t st = static_cast<hipStream_t>(stream);
   return c->dtype == QIDDM_F32 ? dispatch_n<float, true>(c->n_qubits, ptr, p, n_replicas, st)
                                : dispatch_n<double, true>(c->n_qubits, ptr, p, n_replicas, st);
+}
+
+int qiddm_dense_forward(const qiddm_circuit_t* c, const double* x, int64_t batch, int64_t x_ld,
+                        int64_t in_features, const double* w_down, const double* b_down,
+                        const double* angles, const double* w_up, const double* b_up,
+                        int64_t out_features, int32_t post_mode, double noise_factor, double* y,
+                        int64_t y_ld, void* stream) {
+  int rc = check_circuit(c);
+  if (rc != QIDDM_OK) return rc;
+  if (c->encoding != QIDDM_ENC_RZ || c->measure != QIDDM_MEAS_EXPZ)
+    return fail(QIDDM_ERR_UNSUPPORTED, "dense forward needs the RZ encoding and the <Z> read-out");
+  if (batch < 0) return fail(QIDDM_ERR_INVALID, "batch=%lld < 0", (long long)batch);
+  if (in_features < 1 || out_features < 1 || in_features > (1 << 24) || out_features > (1 << 24))
+    return fail(QIDDM_ERR_INVALID, "bad feature counts %lld / %lld", (long long)in_features,
+                (long long)out_features);
+  if (post_mode != 0 && post_mode != 1) return fail(QIDDM_ERR_INVALID, "post_mode must be 0 or 1");
+  if (post_mode == 1 && in_features != out_features)
+    return fail(QIDDM_ERR_INVALID, "post_mode 1 needs out_features == in_features");
+  if (batch == 0) return QIDDM_OK;
+  if (!x || !w_down || !angles || !w_up || !y)
+    return fail(QIDDM_ERR_INVALID, "x/w_down/angles/w_up/y is NULL");
+  if (x == y) return fail(QIDDM_ERR_INVALID, "y must not alias x");
+  if (x_ld < in_features || y_ld < out_features)
+    return fail(QIDDM_ERR_INVALID, "row strides smaller than the feature counts");
+  qiddm::KScalars p = make_params(c);
+  p.batch = batch;
+  qiddm::DenseScalars d;
+  std::memset(&d, 0, sizeof(d));
+  d.x_ld = x_ld;
+  d.y_ld = y_ld;
+  d.in_features = (int32_t)in_features;
+  d.out_features = (int32_t)out_features;
+  d.post_mode = post_mode;
+  d.noise_factor = noise_factor;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return c->dtype == QIDDM_F32
+             ? dispatch_dense<float>(c->n_qubits, x, w_down, b_down, angles, w_up, b_up, y, d, p, st)
+             : dispatch_dense<double>(c->n_qubits, x, w_down, b_down, angles, w_up, b_up, y, d, p, st);
 }
 
 }  // extern "C"

@@ -224,26 +224,61 @@ struct Engine {
     T sign = 0;
   };
 
-  // -- block-level staging (all threads of the block; ends with a barrier) -------------
-  __device__ __forceinline__ void stage(unsigned char* smem, const T* __restrict__ table, int n_rot,
-                                        bool use_cnot, int shift_gate, int shift_var) {
-    T* gates = reinterpret_cast<T*>(smem);
-    uint32_t* cz = reinterpret_cast<uint32_t*>(smem + S::gate_bytes(n_rot));
-    uint32_t* cn_lane = cz + S::kCz;
-    uint32_t* cn_reg = cn_lane + S::kCnLane;
+  // -- block-level staging (all threads of the block): carve, fill_*, then __syncthreads() ----
+  T* s_gates_w;
+  uint32_t* s_tables_w;
+
+  __device__ __forceinline__ void carve(unsigned char* smem, int n_rot) {
+    s_gates_w = reinterpret_cast<T*>(smem);
+    s_tables_w = reinterpret_cast<uint32_t*>(smem + S::gate_bytes(n_rot));
+    s_gates = s_gates_w;
+    s_cz = s_tables_w;
+    s_cn_lane = s_tables_w + S::kCz;
+    s_cn_reg = s_tables_w + S::kCz + S::kCnLane;
     const int tid = threadIdx.x;
-    for (int g = tid; g < n_rot; g += kBlock) {
+    lane = tid & (kWave - 1);
+    sub = lane & (LPS - 1);
+    s_slab = reinterpret_cast<C*>(smem + S::gate_bytes(n_rot) + S::kTableBytes) +
+             (size_t)((tid >> 6) * SPW + (lane >> LB)) * L::D;
+  }
+
+  // LDS image of one gate: [u00, i*u00, u01, i*u01 | u11, i*u11, u10, i*u10]
+  __device__ __forceinline__ static void put_gate(T* d, T u00r, T u00i, T u01r, T u01i, T u10r, T u10i,
+                                                  T u11r, T u11i) {
+    d[0] = u00r;  d[1] = u00i;  d[2] = -u00i;  d[3] = u00r;
+    d[4] = u01r;  d[5] = u01i;  d[6] = -u01i;  d[7] = u01r;
+    d[8] = u11r;  d[9] = u11i;  d[10] = -u11i; d[11] = u11r;
+    d[12] = u10r; d[13] = u10i; d[14] = -u10i; d[15] = u10r;
+  }
+
+  __device__ __forceinline__ void fill_gates_from_table(const T* __restrict__ table, int n_rot,
+                                                        int shift_gate, int shift_var) {
+    for (int g = threadIdx.x; g < n_rot; g += kBlock) {
       const int var = (g == shift_gate) ? shift_var : 0;
       const T* u = table + ((size_t)g * kVariants + var) * kGateReals;
-      T* d = gates + (size_t)g * kLdsGateReals;
-      const T u00r = u[0], u00i = u[1], u01r = u[2], u01i = u[3];
-      const T u10r = u[4], u10i = u[5], u11r = u[6], u11i = u[7];
-      d[0] = u00r;  d[1] = u00i;  d[2] = -u00i;  d[3] = u00r;    // u00, i*u00
-      d[4] = u01r;  d[5] = u01i;  d[6] = -u01i;  d[7] = u01r;    // u01, i*u01
-      d[8] = u11r;  d[9] = u11i;  d[10] = -u11i; d[11] = u11r;   // u11, i*u11
-      d[12] = u10r; d[13] = u10i; d[14] = -u10i; d[15] = u10r;   // u10, i*u10
+      put_gate(s_gates_w + (size_t)g * kLdsGateReals, u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
     }
+  }
+
+  // Rot(phi, theta, omega) = RZ(omega) RY(theta) RZ(phi) straight from the (G, 3) float64 angles
+  __device__ __forceinline__ void fill_gates_from_angles(const double* __restrict__ angles, int n_rot) {
+    for (int g = threadIdx.x; g < n_rot; g += kBlock) {
+      const double phi = angles[g * 3 + 0], theta = angles[g * 3 + 1], omega = angles[g * 3 + 2];
+      double c, s, ca, sa, cb, sb;
+      sincos(0.5 * theta, &s, &c);
+      sincos(0.5 * (phi + omega), &sa, &ca);
+      sincos(0.5 * (phi - omega), &sb, &cb);
+      put_gate(s_gates_w + (size_t)g * kLdsGateReals, (T)(ca * c), (T)(-sa * c), (T)(-cb * s),
+               (T)(-sb * s), (T)(cb * s), (T)(-sb * s), (T)(ca * c), (T)(sa * c));
+    }
+  }
+
+  __device__ __forceinline__ void fill_rings(bool use_cnot) {
     if constexpr (N > 1) {
+      uint32_t* cz = s_tables_w;
+      uint32_t* cn_lane = cz + S::kCz;
+      uint32_t* cn_reg = cn_lane + S::kCnLane;
+      const int tid = threadIdx.x;
       if (use_cnot) {
         for (int i = tid; i < L::NR * kWave; i += kBlock)
           cn_lane[i] = cnot_ring_map<N>((uint32_t)((i % kWave) & (LPS - 1)), i / kWave + 1);
@@ -260,16 +295,6 @@ struct Engine {
         }
       }
     }
-    __syncthreads();
-    s_gates = gates;
-    s_cz = cz;
-    s_cn_lane = cn_lane;
-    s_cn_reg = cn_reg;
-    lane = tid & (kWave - 1);
-    sub = lane & (LPS - 1);
-    const int wave = tid >> 6;
-    s_slab = reinterpret_cast<C*>(smem + S::gate_bytes(n_rot) + S::kTableBytes) +
-             (size_t)(wave * SPW + (lane >> LB)) * L::D;
   }
 
   // -- single-qubit gate on bit Q; matrix halves lo = [u00,iu00,u01,iu01], hi = [u11,iu11,u10,iu10]
@@ -538,7 +563,10 @@ __global__ __launch_bounds__(kBlock) void circuit_kernel(const T* __restrict__ i
     }
   }
   E eng;
-  eng.stage(smem_raw, table, n_rot, p.imprimitive == 0, shift_gate, shift_var);
+  eng.carve(smem_raw, n_rot);
+  eng.fill_gates_from_table(table, n_rot, shift_gate, shift_var);
+  eng.fill_rings(p.imprimitive == 0);
+  __syncthreads();
   const int lane = eng.lane, sub = eng.sub;
   const int wave = threadIdx.x >> 6;
   const int swave = lane >> LB;
@@ -584,6 +612,90 @@ __global__ __launch_bounds__(kBlock) void circuit_kernel(const T* __restrict__ i
         for (int w = 0; w < N; ++w) acc += gout[sample * p.g_ld + w] * result[w];
       }
       if (valid && sub == 0) dots[(int64_t)replica_local * p.batch + sample] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// dense-net kernel: linear_down -> N chained circuit rounds -> linear_up in ONE launch.
+// The whole forward of the reference's QNN_noise / QNN / QIDDM_LL_noise
+// (nn/qdense.py:267-289, 346-368, 1620-1642) and, with post_mode 1, the "noise"-goal
+// update of the sampling loop (src/models.py:130-134) on top of it.  Classical glue in
+// float64 (the reference's dtype), statevector in T.  Gate matrices are built from the
+// raw float64 angles while the workgroup stages its LDS tables: no separate launch.
+// ---------------------------------------------------------------------------
+struct DenseScalars {
+  int64_t x_ld, y_ld;
+  int32_t in_features, out_features;
+  int32_t post_mode;  // 0: y = net(x)   1: y = clamp(x - (net(x) - 0.5) * 0.1 * noise_factor, 0, 1)
+  int32_t pad_;
+  double noise_factor;
+};
+
+template <typename T, int N>
+__global__ __launch_bounds__(kBlock) void dense_forward_kernel(
+    const double* __restrict__ x, const double* __restrict__ wd, const double* __restrict__ bd,
+    const double* __restrict__ angles, const double* __restrict__ wu, const double* __restrict__ bu,
+    double* __restrict__ y, const DenseScalars d, const KScalars p) {
+  using E = Engine<T, N>;
+  using L = typename E::L;
+  constexpr int LB = L::LB, R = L::R, SPW = L::SPW, LPS = L::LPS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int n_rot = p.n_rounds * p.n_blocks * p.sel_layers * N;
+  E eng;
+  eng.carve(smem_raw, n_rot);
+  eng.fill_gates_from_angles(angles, n_rot);
+  eng.fill_rings(p.imprimitive == 0);
+  __syncthreads();
+  const int lane = eng.lane, sub = eng.sub;
+  const int wave = threadIdx.x >> 6;
+  const int swave = lane >> LB;
+  const typename E::Shift no_shift;
+  const int P = d.in_features, Q = d.out_features;
+
+  const int64_t groups = (p.batch + SPW - 1) / SPW;
+  for (int64_t grp = (int64_t)blockIdx.x * kWavesPerBlock + wave; grp < groups;
+       grp += (int64_t)gridDim.x * kWavesPerBlock) {
+    const int64_t sample_raw = grp * SPW + swave;
+    const bool valid = sample_raw < p.batch;
+    const int64_t sample = valid ? sample_raw : p.batch - 1;
+    const double* __restrict__ xrow = x + sample * d.x_ld;
+
+    // ---- linear_down: h_j = b_j + sum_p x_p W[j, p], lanes stride over the pixels ----------
+    double acc[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) acc[j] = 0.0;
+    for (int pix = sub; pix < P; pix += LPS) {
+      const double xv = xrow[pix];
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc[j] = fma(xv, wd[(size_t)j * P + pix], acc[j]);
+    }
+    T xs[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      const double h = group_sum<double, LB>(acc[j], lane) + (bd ? bd[j] : 0.0);
+      xs[j] = (T)(h * p.enc_scale);
+    }
+
+    // ---- the circuit --------------------------------------------------------------------------
+    T result[N], pr[R];
+    eng.run(p, nullptr, xs, no_shift, result, pr);
+    double ev[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) ev[j] = (double)result[j];
+
+    // ---- linear_up (+ optional sampling update) --------------------------------------------
+    double* __restrict__ yrow = y + sample * d.y_ld;
+    for (int pix = sub; pix < Q; pix += LPS) {
+      double o = bu ? bu[pix] : 0.0;
+      const double* __restrict__ wrow = wu + (size_t)pix * N;
+#pragma unroll
+      for (int j = 0; j < N; ++j) o = fma(ev[j], wrow[j], o);
+      if (d.post_mode == 1) {
+        o = xrow[pix] - (o - 0.5) * 0.1 * d.noise_factor;
+        o = fmin(fmax(o, 0.0), 1.0);
+      }
+      if (valid) yrow[pix] = o;
     }
   }
 }

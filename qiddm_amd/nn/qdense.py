@@ -218,9 +218,20 @@ class QNN_noise(_QuantumNet):
         qml.StronglyEntanglingLayers(weights, wires=range(self.hidden_features), imprimitive=qml.ops.CZ)
         return [qml.expval(qml.PauliZ(i)) for i in range(self.hidden_features)]
 
+    def _circuit_descriptor(self):
+        return _c.Circuit(n_qubits=self.hidden_features, encoding="rz", imprimitive="CZ", measure="expz",
+                          n_rounds=1, n_blocks=1, sel_layers=self.qdepth)
+
     def forward(self, x):
         b, c, w, h = x.shape
         flat = x.reshape(b, -1).to(self.linear_down.weight.device).to(torch.double)
+        if self._fused_rounds_ok():
+            # inference: linear_down + circuit + linear_up in one launch
+            circ = self._circuit_descriptor()
+            out = _c.dense_forward(circ, flat, self.linear_down.weight, self.linear_down.bias,
+                                   self.weights.reshape(circ.angles_shape), self.linear_up.weight,
+                                   self.linear_up.bias)
+            return out.view(b, c, w, h)
         reduced = self.linear_down(flat)
         ev = self.qnode(reduced, self.weights)
         if self.detach_quantum:
@@ -407,6 +418,13 @@ class _QIDDMBase(_QuantumNet):
 
     def forward(self, x):
         b, c, w, h = x.shape
+        if self._fused_rounds_ok() and not self._use_pca:
+            # inference: linear_down + N chained rounds + linear_up in one launch
+            circ = _c.Circuit(n_qubits=self.hidden_features, encoding="rz", imprimitive="CZ",
+                              measure="expz", n_rounds=self.N, n_blocks=self.spectrum_layer, sel_layers=2)
+            out = _c.dense_forward(circ, x.reshape(b, -1), self.linear_down.weight, self.linear_down.bias,
+                                   self.weights1, self.linear_up.weight, self.linear_up.bias)
+            return out.to(self.linear_up.weight.dtype).view(b, c, w, h)
         red = self.reduce(x.reshape(b, -1))
         ev = self.quantum_rounds(red)
         ev = ev.to(self.linear_up.weight.device).to(self.linear_up.weight.dtype)

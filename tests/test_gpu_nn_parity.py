@@ -207,3 +207,35 @@ def test_diffusion_training_step_on_device():
     assert torch.allclose(recon.detach().cpu(), ref_recon.abs(), atol=5e-5)
     assert abs(loss.item() - ref_loss.item()) < 1e-5
     assert net.linear_up.weight.grad is not None and net.weights.grad is None   # F1
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 5e-5), ("f64", 1e-10)])
+@pytest.mark.parametrize("n,N,L,S,P", [(8, 1, 1, 14, 784), (8, 2, 6, 2, 784), (4, 1, 2, 2, 64), (2, 2, 1, 3, 10),
+                                       (6, 2, 14, 2, 784), (10, 1, 3, 2, 100)])
+def test_dense_forward_kernel(n, N, L, S, P, precision, tol):
+    """qiddm_dense_forward: linear_down -> rounds -> linear_up in one launch, both post modes,
+    including the sub-wave layouts (n < 6: several samples per wavefront) and a ragged batch."""
+    from qiddm_amd.circuit import Circuit, dense_forward
+    g = torch.Generator().manual_seed(n * 100 + P)
+    B = 45
+    x = torch.rand(B, P, generator=g, dtype=torch.float64)
+    wd = torch.randn(n, P, generator=g, dtype=torch.float64) / P ** 0.5 * 3
+    bd = torch.randn(n, generator=g, dtype=torch.float64)
+    wu = torch.randn(P, n, generator=g, dtype=torch.float64)
+    bu = torch.randn(P, generator=g, dtype=torch.float64) * 0.1
+    w = torch.randn(N, L, S, n, 3, generator=g, dtype=torch.float64) * 0.6
+    circ = Circuit(n_qubits=n, encoding="rz", imprimitive="CZ", measure="expz", n_rounds=N, n_blocks=L,
+                   sel_layers=S)
+    spec = oc.Spec(n=n, encoding="rz", imprimitive="CZ", measure="expz")
+    ref = oc.run_circuit(spec, x @ wd.T + bd, w) @ wu.T + bu
+    dev = lambda t: t.to(DEV)
+    got = dense_forward(circ, dev(x), dev(wd), dev(bd), dev(w), dev(wu), dev(bu), precision).cpu()
+    assert torch.allclose(got, ref, atol=tol, rtol=tol), (got - ref).abs().max()
+    got1 = dense_forward(circ, dev(x), dev(wd), dev(bd), dev(w), dev(wu), dev(bu), precision,
+                         post_mode=1, noise_factor=0.7).cpu()
+    ref1 = torch.clamp(x - (ref - 0.5) * 0.1 * 0.7, 0, 1)
+    assert torch.allclose(got1, ref1, atol=tol, rtol=tol), (got1 - ref1).abs().max()
+    # no biases
+    got2 = dense_forward(circ, dev(x), dev(wd), None, dev(w), dev(wu), None, precision).cpu()
+    ref2 = oc.run_circuit(spec, x @ wd.T, w) @ wu.T
+    assert torch.allclose(got2, ref2, atol=tol, rtol=tol)
