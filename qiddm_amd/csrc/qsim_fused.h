@@ -107,8 +107,16 @@ __device__ __forceinline__ V2<T> times_i(V2<T> a) {
 }
 
 // ---------------------------------------------------------------------------
-// cross-lane exchange: value held by lane (l ^ MASK), VALU only
+// cross-lane exchange, VALU only.  Amplitude indices use LOGICAL lane numbers
+//     logical = physical ^ (3 * bit2(physical))        (an involution)
+// so that flipping logical bit 0 / 1 / 2 is physical xor 1 / 2 / 7: all three are single DPP
+// moves (quad_perm, quad_perm, row_half_mirror).  Bits 3..5 are the same in both numberings.
+// xlane<MASK>(v) returns the value held by the lane whose LOGICAL number differs in bit MASK.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ constexpr int logical_lane(int physical) {
+  return physical ^ (((physical >> 2) & 1) * 3);
+}
+
 template <int MASK>
 __device__ __forceinline__ int xlane_i32(int v, int lane) {
   if constexpr (MASK == 1) {
@@ -116,8 +124,9 @@ __device__ __forceinline__ int xlane_i32(int v, int lane) {
   } else if constexpr (MASK == 2) {
     return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);  // quad_perm [2,3,0,1]
   } else if constexpr (MASK == 4) {
-    const int t = __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);  // row_half_mirror: l ^ 7
-    return __builtin_amdgcn_mov_dpp(t, 0x1B, 0xF, 0xF, true);          // quad_perm [3,2,1,0]: ^ 3
+    // LOGICAL bit 2: lanes are relabelled (logical_lane()) so that flipping it is the single
+    // DPP row_half_mirror (physical lane ^ 7) instead of a two-move xor 4
+    return __builtin_amdgcn_mov_dpp(v, 0x141, 0xF, 0xF, true);
   } else if constexpr (MASK == 8) {
     return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);  // row_ror:8
   } else if constexpr (MASK == 16) {
@@ -217,7 +226,9 @@ struct Engine {
   const uint32_t* s_cn_lane;
   const uint32_t* s_cn_reg;
   C* s_slab;  // this wave's sample slot in the CNOT scratch
-  int lane, sub;
+  int lane;   // physical lane (cross-lane moves, bits 4/5 selects)
+  int llane;  // logical lane (amplitude indices, table rows, gate halves)
+  int sub;    // logical lane within the sample
 
   struct Shift {
     int blk = -1, wire = 0;  // shifted input-angle occurrence (block, wire)
@@ -237,9 +248,10 @@ struct Engine {
     s_cn_reg = s_tables_w + S::kCz + S::kCnLane;
     const int tid = threadIdx.x;
     lane = tid & (kWave - 1);
-    sub = lane & (LPS - 1);
+    llane = logical_lane(lane);
+    sub = llane & (LPS - 1);
     s_slab = reinterpret_cast<C*>(smem + S::gate_bytes(n_rot) + S::kTableBytes) +
-             (size_t)((tid >> 6) * SPW + (lane >> LB)) * L::D;
+             (size_t)((tid >> 6) * SPW + (llane >> LB)) * L::D;
   }
 
   // LDS image of one gate: [u00, i*u00, u01, i*u01 | u11, i*u11, u10, i*u10]
@@ -297,10 +309,10 @@ struct Engine {
     }
   }
 
-  // -- single-qubit gate on bit Q; matrix halves lo = [u00,iu00,u01,iu01], hi = [u11,iu11,u10,iu10]
-  template <int Q>
-  __device__ __forceinline__ void gate_regs(C (&a)[R], const C (&lo)[4], const C (&hi)[4]) const {
-    constexpr int J = 1 << (Q - LB);
+  // -- single-qubit gate between register pairs (r, r|J); matrix halves
+  //    lo = [u00,iu00,u01,iu01] (row of the bit-clear amplitude), hi = [u11,iu11,u10,iu10]
+  template <int J>
+  __device__ __forceinline__ void gate_regs(C (&a)[R], const C* lo, const C* hi) const {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if ((r & J) == 0) {
@@ -310,8 +322,9 @@ struct Engine {
       }
     }
   }
+  // -- gate on lane bit Q; h = the half that matches this lane's bit: [own, i*own, partner, i*partner]
   template <int Q>
-  __device__ __forceinline__ void gate_lane(C (&a)[R], const C (&h)[4]) const {
+  __device__ __forceinline__ void gate_lane(C (&a)[R], const C* h) const {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const C own = a[r];
@@ -319,30 +332,110 @@ struct Engine {
       a[r] = cfma<T>(par, h[2], h[3], cmul2<T>(own, h[0], h[1]));
     }
   }
-
-  // -- one Rot layer from the LDS gate table ------------------------------------------
-  template <int W>
-  __device__ __forceinline__ void rot_layer(C (&a)[R], int gate0) const {
-    if constexpr (W < N) {
-      constexpr int Q = N - 1 - W;
-      const C* gp = reinterpret_cast<const C*>(s_gates + (size_t)(gate0 + W) * kLdsGateReals);
-      if constexpr (Q >= LB) {
-        C lo[4], hi[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          lo[i] = gp[i];
-          hi[i] = gp[4 + i];
-        }
-        gate_regs<Q>(a, lo, hi);
-      } else {
-        const C* hp = gp + (((lane >> Q) & 1) << 2);
-        C h[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) h[i] = hp[i];
-        gate_lane<Q>(a, h);
-      }
-      rot_layer<W + 1>(a, gate0);
+  // -- exchange register bit 0 with lane bit Q (4: v_permlane16_swap, 5: v_permlane32_swap).
+  //    Afterwards a[r] / a[r|1] hold the amplitudes whose OLD lane bit Q is 0 / 1, so a gate on
+  //    that qubit is register-local with wave-uniform coefficients.  The exchange is an involution.
+  template <int Q>
+  __device__ __forceinline__ static void swap_dword(int& x, int& y) {
+    if constexpr (Q == 5) {
+      const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)y, false, false);
+      x = (int)r[0];
+      y = (int)r[1];
+    } else {
+      const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)y, false, false);
+      x = (int)r[0];
+      y = (int)r[1];
     }
+  }
+  template <int Q>
+  __device__ __forceinline__ static void swap_real(float& x, float& y) {
+    int xi = __float_as_int(x), yi = __float_as_int(y);
+    swap_dword<Q>(xi, yi);
+    x = __int_as_float(xi);
+    y = __int_as_float(yi);
+  }
+  template <int Q>
+  __device__ __forceinline__ static void swap_real(double& x, double& y) {
+    int xl = __double2loint(x), xh = __double2hiint(x), yl = __double2loint(y), yh = __double2hiint(y);
+    swap_dword<Q>(xl, yl);
+    swap_dword<Q>(xh, yh);
+    x = __hiloint2double(xh, xl);
+    y = __hiloint2double(yh, yl);
+  }
+  template <int Q>
+  __device__ __forceinline__ void swap_reg0_with_lane_bit(C (&a)[R]) const {
+#pragma unroll
+    for (int r = 0; r < R; r += 2) {
+      T x0 = a[r].x, y0 = a[r].y, x1 = a[r + 1].x, y1 = a[r + 1].y;
+      swap_real<Q>(x0, x1);
+      swap_real<Q>(y0, y1);
+      a[r] = C{x0, y0};
+      a[r + 1] = C{x1, y1};
+    }
+  }
+
+  // how the gate on wire W (bit Q = N-1-W) is executed
+  enum Kind { kReg, kSwap, kLane };
+  template <int W>
+  static constexpr Kind kind_of() {
+    constexpr int Q = N - 1 - W;
+    if (Q >= LB) return kReg;
+    if ((Q == 4 || Q == 5) && R >= 2) return kSwap;
+    return kLane;
+  }
+
+  // -- LDS -> registers: whole matrix (8 complex) or this lane's half (4 complex) ------------
+  template <int W>
+  __device__ __forceinline__ void load_gate(int gate0, C (&m)[8]) const {
+    constexpr int Q = N - 1 - W;
+    const C* gp = reinterpret_cast<const C*>(s_gates + (size_t)(gate0 + W) * kLdsGateReals);
+    if constexpr (kind_of<W>() == kLane) {
+      const C* hp = gp + (((llane >> Q) & 1) << 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) m[i] = hp[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) m[i] = gp[i];
+    }
+  }
+  template <int W>
+  __device__ __forceinline__ void apply_loaded(C (&a)[R], const C (&m)[8]) const {
+    constexpr int Q = N - 1 - W;
+    if constexpr (kind_of<W>() == kReg) {
+      gate_regs<(1 << (Q >= LB ? Q - LB : 0))>(a, m, m + 4);
+    } else if constexpr (kind_of<W>() == kSwap) {
+      swap_reg0_with_lane_bit<Q>(a);
+      gate_regs<1>(a, m, m + 4);
+      swap_reg0_with_lane_bit<Q>(a);
+    } else {
+      gate_lane<Q>(a, m);
+    }
+  }
+
+  // -- one Rot layer.  `cur` holds the (prefetched) matrix of wire 0; while gate W runs the
+  //    matrix of gate W+1 is already in flight; on return `cur` holds wire 0 of `next_gate0`.
+  template <int W>
+  __device__ __forceinline__ void rot_steps(C (&a)[R], int gate0, int next_gate0, C (&cur)[8],
+                                            C (&carry)[8]) const {
+    C nxt[8];
+    if constexpr (W + 1 < N) {
+      load_gate<W + 1>(gate0, nxt);
+    } else {
+      load_gate<0>(next_gate0, nxt);
+    }
+    apply_loaded<W>(a, cur);
+    if constexpr (W + 1 < N) {
+      rot_steps<W + 1>(a, gate0, next_gate0, nxt, carry);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) carry[i] = nxt[i];
+    }
+  }
+  __device__ __forceinline__ void rot_layer(C (&a)[R], int gate0, int next_gate0, C (&cur)[8]) const {
+    C carry[8];
+    rot_steps<0>(a, gate0, next_gate0, cur, carry);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cur[i] = carry[i];
   }
 
   // -- per-sample RY(x_w) layer (qml.AngleEmbedding rotation="Y") -----------------------
@@ -352,11 +445,10 @@ struct Engine {
       constexpr int Q = N - 1 - W;
       const T c = cs[W], s = sn[W], z = 0;
       if constexpr (Q >= LB) {
-        const C lo[4] = {C{c, z}, C{z, c}, C{-s, z}, C{z, -s}};
-        const C hi[4] = {C{c, z}, C{z, c}, C{s, z}, C{z, s}};
-        gate_regs<Q>(a, lo, hi);
+        const C m[8] = {C{c, z}, C{z, c}, C{-s, z}, C{z, -s}, C{c, z}, C{z, c}, C{s, z}, C{z, s}};
+        gate_regs<(1 << (Q >= LB ? Q - LB : 0))>(a, m, m + 4);
       } else {
-        const T sp = ((lane >> Q) & 1) ? s : -s;
+        const T sp = ((llane >> Q) & 1) ? s : -s;
         const C h[4] = {C{c, z}, C{z, c}, C{sp, z}, C{z, sp}};
         gate_lane<Q>(a, h);
       }
@@ -368,14 +460,14 @@ struct Engine {
   __device__ __forceinline__ void ring(C (&a)[R], int ri, bool use_cnot) const {
     if constexpr (N > 1) {
       if (!use_cnot) {
-        const uint32_t bits = s_cz[ri * kWave + lane];
+        const uint32_t bits = s_cz[ri * kWave + llane];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const uint32_t sb = ((bits >> r) & 1u) << 31;
           a[r] = C{flip_sign(a[r].x, sb), flip_sign(a[r].y, sb)};
         }
       } else {
-        const uint32_t lane_term = s_cn_lane[ri * kWave + lane];
+        const uint32_t lane_term = s_cn_lane[ri * kWave + llane];
 #pragma unroll
         for (int r = 0; r < R; ++r) s_slab[lane_term ^ s_cn_reg[ri * R + r]] = a[r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -400,11 +492,12 @@ struct Engine {
       for (int j = 0; j < N; ++j) mine = fma((T)(sub == j ? 1 : 0), xs[j], mine);
       T s, c;
       qsincos(mine * (T)0.5, &s, &c);
-      const int base = lane & ~(LPS - 1);
+      const int base = llane & ~(LPS - 1);
 #pragma unroll
       for (int j = 0; j < N; ++j) {
-        cs[j] = __shfl(c, base | j, kWave);
-        sn[j] = __shfl(s, base | j, kWave);
+        const int src = logical_lane(base | j);  // physical lane of logical lane (base | j)
+        cs[j] = __shfl(c, src, kWave);
+        sn[j] = __shfl(s, src, kWave);
       }
     } else {
 #pragma unroll
@@ -418,7 +511,7 @@ struct Engine {
 #pragma unroll
     for (int q = 0; q < LB; ++q) {  // lane bits: wire N-1-q
       const T c = cs[N - 1 - q];
-      const T si = ((lane >> q) & 1) ? sn[N - 1 - q] : -sn[N - 1 - q];
+      const T si = ((llane >> q) & 1) ? sn[N - 1 - q] : -sn[N - 1 - q];
       const T nr = accr * c - acci * si;
       acci = accr * si + acci * c;
       accr = nr;
@@ -446,6 +539,9 @@ struct Engine {
     C a[R];
     C dx[R];
     T cs[N], sn[N];
+    const int n_rot = p.n_rounds * p.n_blocks * p.sel_layers * N;
+    C gate_m[8];  // matrix of the next wire-0 gate, prefetched one layer ahead
+    load_gate<0>(0, gate_m);
     for (int round = 0; round < p.n_rounds; ++round) {
       // ---- state preparation ---------------------------------------------------------
       if (p.encoding == 1) {
@@ -500,7 +596,9 @@ struct Engine {
           ry_layer<0>(a, cs, sn);
         }
         for (int s = 0; s < p.sel_layers; ++s) {
-          rot_layer<0>(a, ((round * p.n_blocks + blk) * p.sel_layers + s) * N);
+          const int gate0 = ((round * p.n_blocks + blk) * p.sel_layers + s) * N;
+          const int next0 = gate0 + N < n_rot ? gate0 + N : 0;  // last layer: any valid gate
+          rot_layer(a, gate0, next0, gate_m);
           if constexpr (N > 1) ring(a, s % (N - 1), use_cnot);
         }
       }
@@ -524,7 +622,7 @@ struct Engine {
         for (int j = 0; j < N; ++j) {
           const T v = (p.measure == 1)
                           ? result[j]
-                          : __shfl(pr[0], (lane & ~(LPS - 1)) | (j & (LPS - 1)), kWave);
+                          : __shfl(pr[0], logical_lane((llane & ~(LPS - 1)) | (j & (LPS - 1))), kWave);
           xs[j] = v * (T)p.enc_scale;
         }
       }
@@ -569,7 +667,7 @@ __global__ __launch_bounds__(kBlock) void circuit_kernel(const T* __restrict__ i
   __syncthreads();
   const int lane = eng.lane, sub = eng.sub;
   const int wave = threadIdx.x >> 6;
-  const int swave = lane >> LB;
+  const int swave = eng.llane >> LB;
 
   const int64_t groups = (p.batch + SPW - 1) / SPW;
   for (int64_t grp = (int64_t)blockIdx.x * kWavesPerBlock + wave; grp < groups;
@@ -649,7 +747,7 @@ __global__ __launch_bounds__(kBlock) void dense_forward_kernel(
   __syncthreads();
   const int lane = eng.lane, sub = eng.sub;
   const int wave = threadIdx.x >> 6;
-  const int swave = lane >> LB;
+  const int swave = eng.llane >> LB;
   const typename E::Shift no_shift;
   const int P = d.in_features, Q = d.out_features;
 
