@@ -32,8 +32,8 @@
 namespace qiddm {
 
 constexpr int kWave = 64;
-constexpr int kWavesPerBlock = 4;
-constexpr int kBlock = kWave * kWavesPerBlock;
+constexpr int kMaxWavesPerBlock = 8;  // workgroups are 4 or 8 waves (chosen by the host)
+constexpr int kMaxBlock = kWave * kMaxWavesPerBlock;
 constexpr int kVariants = 7;       // global gate table: base + six parameter shifts
 constexpr int kGateReals = 8;      // global gate table: u00 u01 u10 u11 as (re, im)
 constexpr int kLdsGateReals = 16;  // LDS gate table, see above
@@ -84,6 +84,28 @@ __device__ __forceinline__ void qsincos(float x, float* s, float* c) {
   *c = (float)(((q + 1) & 2) ? -cc : cc);
 }
 __device__ __forceinline__ void qsincos(double x, double* s, double* c) { sincos(x, s, c); }
+
+// sin/cos in double, accurate to ~1e-9 (ample for a value that is then rounded to float):
+// used to build the float gate tables from the float64 angles inside the launch.
+__device__ __forceinline__ void sincos_for_f32_table(double x, double* s, double* c) {
+  const double kd = rint(x * 0.63661977236758134308);
+  double r = fma(-kd, 1.57079632679489655800e+00, x);
+  r = fma(-kd, 6.12323399573676603587e-17, r);
+  const double z = r * r, w = z * z;
+  const double sp = (r + (z * r) * (-0.166666666416265235595 + z * 0.0083333293858894631756)) +
+                    (z * r) * w * (-0.000198393348360966317347 + z * 0.0000027183114939898219064);
+  const double cp = ((1.0 + z * -0.499999997251031003120) + w * 0.0416666233237390631894) +
+                    (w * z) * (-0.00138867637746099294692 + z * 0.0000243904487962774090654);
+  const int q = (int)(long long)kd & 3;
+  const double ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+  *s = (q & 2) ? -ss : ss;
+  *c = ((q + 1) & 2) ? -cc : cc;
+}
+template <typename T>
+__device__ __forceinline__ void table_sincos(double x, double* s, double* c) {
+  if constexpr (sizeof(T) == 4) sincos_for_f32_table(x, s, c);
+  else sincos(x, s, c);
+}
 __device__ __forceinline__ float qsqrt(float x) { return sqrtf(x); }
 __device__ __forceinline__ double qsqrt(double x) { return sqrt(x); }
 
@@ -204,10 +226,12 @@ struct Smem {
   static constexpr int kCnLane = L::NR * kWave;  // u32 [range][lane]
   static constexpr int kCnReg = L::NR * L::R;    // u32 [range][r]
   static constexpr size_t kTableBytes = ((size_t)(kCz + kCnLane + kCnReg) * 4 + 15) / 16 * 16;
-  static constexpr size_t kScratchBytes = (size_t)kWavesPerBlock * kWave * L::R * 2 * sizeof(T);
+  __host__ __device__ static size_t scratch_bytes(int waves) {
+    return (size_t)waves * kWave * L::R * 2 * sizeof(T);
+  }
   __host__ __device__ static size_t gate_bytes(int64_t n_rot) { return (size_t)n_rot * kLdsGateReals * sizeof(T); }
-  __host__ __device__ static size_t bytes(int64_t n_rot, bool cnot) {
-    return gate_bytes(n_rot) + kTableBytes + (cnot ? kScratchBytes : 0);
+  __host__ __device__ static size_t bytes(int64_t n_rot, bool cnot, int waves) {
+    return gate_bytes(n_rot) + kTableBytes + (cnot ? scratch_bytes(waves) : 0);
   }
 };
 
@@ -265,7 +289,7 @@ struct Engine {
 
   __device__ __forceinline__ void fill_gates_from_table(const T* __restrict__ table, int n_rot,
                                                         int shift_gate, int shift_var) {
-    for (int g = threadIdx.x; g < n_rot; g += kBlock) {
+    for (int g = threadIdx.x; g < n_rot; g += blockDim.x) {
       const int var = (g == shift_gate) ? shift_var : 0;
       const T* u = table + ((size_t)g * kVariants + var) * kGateReals;
       put_gate(s_gates_w + (size_t)g * kLdsGateReals, u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7]);
@@ -274,12 +298,12 @@ struct Engine {
 
   // Rot(phi, theta, omega) = RZ(omega) RY(theta) RZ(phi) straight from the (G, 3) float64 angles
   __device__ __forceinline__ void fill_gates_from_angles(const double* __restrict__ angles, int n_rot) {
-    for (int g = threadIdx.x; g < n_rot; g += kBlock) {
+    for (int g = threadIdx.x; g < n_rot; g += blockDim.x) {
       const double phi = angles[g * 3 + 0], theta = angles[g * 3 + 1], omega = angles[g * 3 + 2];
       double c, s, ca, sa, cb, sb;
-      sincos(0.5 * theta, &s, &c);
-      sincos(0.5 * (phi + omega), &sa, &ca);
-      sincos(0.5 * (phi - omega), &sb, &cb);
+      table_sincos<T>(0.5 * theta, &s, &c);
+      table_sincos<T>(0.5 * (phi + omega), &sa, &ca);
+      table_sincos<T>(0.5 * (phi - omega), &sb, &cb);
       put_gate(s_gates_w + (size_t)g * kLdsGateReals, (T)(ca * c), (T)(-sa * c), (T)(-cb * s),
                (T)(-sb * s), (T)(cb * s), (T)(-sb * s), (T)(ca * c), (T)(sa * c));
     }
@@ -292,12 +316,12 @@ struct Engine {
       uint32_t* cn_reg = cn_lane + S::kCnLane;
       const int tid = threadIdx.x;
       if (use_cnot) {
-        for (int i = tid; i < L::NR * kWave; i += kBlock)
+        for (int i = tid; i < L::NR * kWave; i += blockDim.x)
           cn_lane[i] = cnot_ring_map<N>((uint32_t)((i % kWave) & (LPS - 1)), i / kWave + 1);
-        for (int i = tid; i < L::NR * R; i += kBlock)
+        for (int i = tid; i < L::NR * R; i += blockDim.x)
           cn_reg[i] = cnot_ring_map<N>((uint32_t)(i % R) << LB, i / R + 1);
       } else {
-        for (int i = tid; i < L::NR * kWave; i += kBlock) {
+        for (int i = tid; i < L::NR * kWave; i += blockDim.x) {
           const uint32_t ls = (uint32_t)((i % kWave) & (LPS - 1));
           uint32_t bits = 0;
 #pragma unroll
@@ -424,6 +448,9 @@ struct Engine {
       load_gate<0>(next_gate0, nxt);
     }
     apply_loaded<W>(a, cur);
+    // keep the one-ahead prefetch but stop the scheduler from hoisting further gates' LDS reads
+    // above this point (it otherwise runs the kernel into the 256-VGPR wall and spills)
+    __builtin_amdgcn_sched_barrier(0);
     if constexpr (W + 1 < N) {
       rot_steps<W + 1>(a, gate0, next_gate0, nxt, carry);
     } else {
@@ -634,7 +661,7 @@ struct Engine {
 // circuit kernel: inputs -> probabilities / <Z>   (SHIFT: -> dot with upstream grad)
 // ---------------------------------------------------------------------------
 template <typename T, int N, bool SHIFT>
-__global__ __launch_bounds__(kBlock) void circuit_kernel(const T* __restrict__ inputs,
+__global__ __launch_bounds__(4 * kWave) void circuit_kernel(const T* __restrict__ inputs,
                                                          const T* __restrict__ table,
                                                          T* __restrict__ out,
                                                          const T* __restrict__ gout,
@@ -670,8 +697,9 @@ __global__ __launch_bounds__(kBlock) void circuit_kernel(const T* __restrict__ i
   const int swave = eng.llane >> LB;
 
   const int64_t groups = (p.batch + SPW - 1) / SPW;
-  for (int64_t grp = (int64_t)blockIdx.x * kWavesPerBlock + wave; grp < groups;
-       grp += (int64_t)gridDim.x * kWavesPerBlock) {
+  const int waves_per_block = blockDim.x >> 6;
+  for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < groups;
+       grp += (int64_t)gridDim.x * waves_per_block) {
     const int64_t sample_raw = grp * SPW + swave;
     const bool valid = sample_raw < p.batch;
     const int64_t sample = valid ? sample_raw : p.batch - 1;
@@ -728,10 +756,11 @@ struct DenseScalars {
   int32_t post_mode;  // 0: y = net(x)   1: y = clamp(x - (net(x) - 0.5) * 0.1 * noise_factor, 0, 1)
   int32_t pad_;
   double noise_factor;
+  unsigned long long* stamps;  // diagnostics only (tools/stamp_dense.py): s_memtime at phase ends
 };
 
-template <typename T, int N>
-__global__ __launch_bounds__(kBlock) void dense_forward_kernel(
+template <typename T, int N, bool LDSW, int WPB, int U = (WPB >= 4 ? 4 : 7)>
+__global__ __launch_bounds__(WPB * kWave) void dense_forward_kernel(
     const double* __restrict__ x, const double* __restrict__ wd, const double* __restrict__ bd,
     const double* __restrict__ angles, const double* __restrict__ wu, const double* __restrict__ bu,
     double* __restrict__ y, const DenseScalars d, const KScalars p) {
@@ -740,20 +769,32 @@ __global__ __launch_bounds__(kBlock) void dense_forward_kernel(
   constexpr int LB = L::LB, R = L::R, SPW = L::SPW, LPS = L::LPS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n_rot = p.n_rounds * p.n_blocks * p.sel_layers * N;
+  const int P = d.in_features, Q = d.out_features;
+  const bool stamp = d.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0;
+  if (stamp) d.stamps[0] = __builtin_amdgcn_s_memtime();
   E eng;
   eng.carve(smem_raw, n_rot);
+  // LDSW: both weight matrices live in LDS as [j][pixel] float64 (w_up transposed while staging),
+  // so the per-sample GEMV loops read conflict-free consecutive ds_read_b64 instead of L2.
+  double* s_wd = reinterpret_cast<double*>(smem_raw + Smem<T, N>::bytes(n_rot, p.imprimitive == 0, blockDim.x >> 6));
+  double* s_wu = s_wd + (size_t)N * P;
+  if constexpr (LDSW) {
+    for (int i = threadIdx.x; i < N * P; i += blockDim.x) s_wd[i] = wd[i];
+    for (int i = threadIdx.x; i < N * Q; i += blockDim.x) s_wu[(size_t)(i % N) * Q + i / N] = wu[i];
+  }
   eng.fill_gates_from_angles(angles, n_rot);
   eng.fill_rings(p.imprimitive == 0);
   __syncthreads();
+  if (stamp) d.stamps[1] = __builtin_amdgcn_s_memtime();
   const int lane = eng.lane, sub = eng.sub;
   const int wave = threadIdx.x >> 6;
   const int swave = eng.llane >> LB;
   const typename E::Shift no_shift;
-  const int P = d.in_features, Q = d.out_features;
 
   const int64_t groups = (p.batch + SPW - 1) / SPW;
-  for (int64_t grp = (int64_t)blockIdx.x * kWavesPerBlock + wave; grp < groups;
-       grp += (int64_t)gridDim.x * kWavesPerBlock) {
+  const int waves_per_block = blockDim.x >> 6;
+  for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < groups;
+       grp += (int64_t)gridDim.x * waves_per_block) {
     const int64_t sample_raw = grp * SPW + swave;
     const bool valid = sample_raw < p.batch;
     const int64_t sample = valid ? sample_raw : p.batch - 1;
@@ -763,10 +804,23 @@ __global__ __launch_bounds__(kBlock) void dense_forward_kernel(
     double acc[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) acc[j] = 0.0;
-    for (int pix = sub; pix < P; pix += LPS) {
-      const double xv = xrow[pix];
+    for (int p0 = sub; p0 < P; p0 += LPS * U) {
+      double xv[U];
 #pragma unroll
-      for (int j = 0; j < N; ++j) acc[j] = fma(xv, wd[(size_t)j * P + pix], acc[j]);
+      for (int u = 0; u < U; ++u) {
+        const int pix = p0 + u * LPS;
+        xv[u] = pix < P ? xrow[pix] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pix = p0 + u * LPS;
+        const int pc = pix < P ? pix : 0;  // xv is 0 there
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const double wv = LDSW ? s_wd[(size_t)j * P + pc] : wd[(size_t)j * P + pc];
+          acc[j] = fma(xv[u], wv, acc[j]);
+        }
+      }
     }
     T xs[N];
 #pragma unroll
@@ -775,26 +829,45 @@ __global__ __launch_bounds__(kBlock) void dense_forward_kernel(
       xs[j] = (T)(h * p.enc_scale);
     }
 
+    if (stamp) d.stamps[2] = __builtin_amdgcn_s_memtime();
     // ---- the circuit --------------------------------------------------------------------------
     T result[N], pr[R];
     eng.run(p, nullptr, xs, no_shift, result, pr);
     double ev[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) ev[j] = (double)result[j];
+    if (stamp) d.stamps[3] = __builtin_amdgcn_s_memtime();
 
     // ---- linear_up (+ optional sampling update) --------------------------------------------
     double* __restrict__ yrow = y + sample * d.y_ld;
-    for (int pix = sub; pix < Q; pix += LPS) {
-      double o = bu ? bu[pix] : 0.0;
-      const double* __restrict__ wrow = wu + (size_t)pix * N;
+    for (int p0 = sub; p0 < Q; p0 += LPS * U) {
+      double o[U], xin[U];
 #pragma unroll
-      for (int j = 0; j < N; ++j) o = fma(ev[j], wrow[j], o);
-      if (d.post_mode == 1) {
-        o = xrow[pix] - (o - 0.5) * 0.1 * d.noise_factor;
-        o = fmin(fmax(o, 0.0), 1.0);
+      for (int u = 0; u < U; ++u) {
+        const int pix = p0 + u * LPS;
+        const int pc = pix < Q ? pix : 0;
+        o[u] = bu ? bu[pc] : 0.0;
+        xin[u] = d.post_mode == 1 ? xrow[pc] : 0.0;
       }
-      if (valid) yrow[pix] = o;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pix = p0 + u * LPS;
+        const int pc = pix < Q ? pix : 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const double wv = LDSW ? s_wu[(size_t)j * Q + pc] : wu[(size_t)pc * N + j];
+          o[u] = fma(ev[j], wv, o[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int pix = p0 + u * LPS;
+        double v = o[u];
+        if (d.post_mode == 1) v = fmin(fmax(xin[u] - (v - 0.5) * 0.1 * d.noise_factor, 0.0), 1.0);
+        if (valid && pix < Q) yrow[pix] = v;
+      }
     }
+    if (stamp) d.stamps[4] = __builtin_amdgcn_s_memtime();
   }
 }
 
