@@ -50,6 +50,7 @@ extern "C" {
 
 #define QIDDM_ABI_VERSION 1
 #define QIDDM_MAX_QUBITS_FUSED 10 /* one wavefront owns the whole slab in registers */
+#define QIDDM_MAX_QUBITS 16       /* 11..16: one workgroup per sample, tiled passes over a workspace slab */
 
 typedef enum qiddm_status {
   QIDDM_OK = 0,
@@ -81,7 +82,7 @@ typedef enum qiddm_dtype {
 } qiddm_dtype;
 
 typedef struct qiddm_circuit {
-  int32_t n_qubits;    /* 1 .. qiddm_max_qubits()                                            */
+  int32_t n_qubits;    /* 1 .. qiddm_max_qubits() (= 16)                                     */
   int32_t encoding;    /* qiddm_encoding                                                     */
   int32_t imprimitive; /* qiddm_imprimitive                                                  */
   int32_t measure;     /* qiddm_measure                                                      */
@@ -111,6 +112,10 @@ int64_t qiddm_gate_table_elems(const qiddm_circuit_t *circ);
 /* replicas of a full parameter-shift sweep: 6*num_rot_gates (+ 2*n_blocks*n for the
  * input angles of RZ/RY encodings)                                                       */
 int64_t qiddm_num_shift_replicas(const qiddm_circuit_t *circ, int with_inputs);
+/* bytes of device workspace qiddm_forward (n_replicas = 0) / qiddm_forward_shifted need for this
+ * circuit and batch: 0 for n <= 10 (register-resident slabs); for n = 11..16 one 2^n-amplitude slab
+ * per concurrently resident workgroup (it stays L2 / Infinity-Cache resident).                   */
+int64_t qiddm_workspace_bytes(const qiddm_circuit_t *circ, int64_t batch, int64_t n_replicas);
 
 /* ---- gate table ----------------------------------------------------------
  * angles: (n_rounds, n_blocks, sel_layers, n, 3) float64, the weights tensor of
@@ -129,10 +134,13 @@ int qiddm_prepare_gates(const qiddm_circuit_t *circ, const double *angles, void 
  * (reference nn/qdense.py:58, 279, 465, 1439, 1633).
  * inputs: (batch, in_ld) row-major, first n_features columns read (may be NULL
  *         for QIDDM_ENC_NONE).  out: (batch, out_ld) rows of 2^n probabilities or
- *         n expectation values.  One wavefront owns one sample's 2^n-amplitude
- *         slab for the whole circuit (n <= 10: registers).                                */
+ *         n expectation values.  n <= 10: one wavefront owns one sample's slab in
+ *         registers for the whole circuit.  n = 11..16: one workgroup per sample, slab in
+ *         `workspace` (>= qiddm_workspace_bytes(circ, batch, 0) bytes; may be NULL for
+ *         n <= 10), tiled passes (qiddm_amd/csrc/qsim_tiled.h).                            */
 int qiddm_forward(const qiddm_circuit_t *circ, const void *inputs, int64_t batch, int64_t in_ld,
-                  const void *gate_table, void *out, int64_t out_ld, void *stream);
+                  const void *gate_table, void *out, int64_t out_ld, void *workspace,
+                  int64_t workspace_bytes, void *stream);
 
 /* ---- parameter-shift sweep ---------------------------------------------------
  * Replaces PennyLane's diff_method="parameter-shift" executions configured at
@@ -147,7 +155,7 @@ int qiddm_forward(const qiddm_circuit_t *circ, const void *inputs, int64_t batch
 int qiddm_forward_shifted(const qiddm_circuit_t *circ, const void *inputs, int64_t batch,
                           int64_t in_ld, const void *gate_table, const void *grad_out,
                           int64_t g_ld, int64_t first_replica, int64_t n_replicas, void *dots,
-                          void *stream);
+                          void *workspace, int64_t workspace_bytes, void *stream);
 
 /* ---- fused dense-net forward ------------------------------------------------------
  * Replaces the whole forward of the reference's linear_down -> quantum rounds -> linear_up

@@ -33,6 +33,7 @@ EXPORTS = (
     "qiddm_gate_count",
     "qiddm_gate_table_elems",
     "qiddm_num_shift_replicas",
+    "qiddm_workspace_bytes",
     "qiddm_prepare_gates",
     "qiddm_forward",
     "qiddm_forward_shifted",
@@ -87,9 +88,11 @@ def _declare(lib):
     lib.qiddm_prepare_gates.restype = ctypes.c_int
     lib.qiddm_prepare_gates.argtypes = [P, vp, vp, vp]
     lib.qiddm_forward.restype = ctypes.c_int
-    lib.qiddm_forward.argtypes = [P, vp, i64, i64, vp, vp, i64, vp]
+    lib.qiddm_forward.argtypes = [P, vp, i64, i64, vp, vp, i64, vp, i64, vp]
     lib.qiddm_forward_shifted.restype = ctypes.c_int
-    lib.qiddm_forward_shifted.argtypes = [P, vp, i64, i64, vp, vp, i64, i64, i64, vp, vp]
+    lib.qiddm_forward_shifted.argtypes = [P, vp, i64, i64, vp, vp, i64, i64, i64, vp, vp, i64, vp]
+    lib.qiddm_workspace_bytes.restype = i64
+    lib.qiddm_workspace_bytes.argtypes = [P, i64, i64]
     lib.qiddm_dense_forward.restype = ctypes.c_int
     lib.qiddm_dense_forward.argtypes = [P, vp, i64, i64, i64, vp, vp, vp, vp, vp, i64, ctypes.c_int32,
                                         ctypes.c_double, vp, i64, vp]

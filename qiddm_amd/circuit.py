@@ -137,6 +137,27 @@ def _prep_inputs(circ: Circuit, inputs, dtype, device):
     return x, x.shape[1], circ
 
 
+_workspaces = {}
+
+
+def _workspace(circ: Circuit, precision: str, batch: int, n_replicas: int, device):
+    """Per-device scratch for the n > 10 tiled kernel (slabs of concurrently resident workgroups).
+    Returns (ptr, nbytes); (0, 0) when the circuit is register-resident."""
+    lib = _capi.lib()
+    cs = circ.c_struct(precision)
+    need = lib.qiddm_workspace_bytes(ctypes.byref(cs), batch, n_replicas)
+    if need < 0:
+        _capi.check(-1)
+    if need == 0:
+        return 0, 0
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < need:
+        buf = torch.empty(need, dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf.data_ptr(), need
+
+
 def prepare_gates(circ: Circuit, angles: torch.Tensor, precision: str) -> torch.Tensor:
     """angles (N,L,S,n,3) -> gate table (G,7,8) of the compute dtype, on device."""
     _require_device(angles, "the circuit weights")
@@ -171,8 +192,9 @@ def run_forward(circ: Circuit, inputs, angles: torch.Tensor, precision: str | No
         table = prepare_gates(circ, angles, precision)
     out = torch.empty(batch, circ.out_cols, dtype=dtype, device=device)
     cs = circ.c_struct(precision)
+    ws_ptr, ws_bytes = _workspace(circ, precision, batch, 0, device)
     _capi.check(lib.qiddm_forward(ctypes.byref(cs), x.data_ptr(), batch, ld, table.data_ptr(),
-                                  out.data_ptr(), circ.out_cols, _stream_ptr(device)))
+                                  out.data_ptr(), circ.out_cols, ws_ptr, ws_bytes, _stream_ptr(device)))
     return out
 
 
@@ -228,15 +250,18 @@ def run_shift_sweep(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch
     total = lib.qiddm_num_shift_replicas(ctypes.byref(cs), 1 if want_inputs else 0)
     n_rot = lib.qiddm_num_rot_gates(ctypes.byref(cs))
     chunk = max(2, min(65534, (max_dots_elems // max(batch, 1)) // 2 * 2, total))
+    if circ.n_qubits > 10:
+        chunk = min(chunk, 256)   # bounds the tiled kernel's workspace (one slab per replica x block)
     w_sum = torch.empty(6 * n_rot, dtype=torch.float64, device=device)
     in_dots = []
     first = 0
     while first < total:
         cnt = min(chunk, total - first)
         dots = torch.empty(cnt, batch, dtype=dtype, device=device)
+        ws_ptr, ws_bytes = _workspace(circ, precision, batch, cnt, device)
         _capi.check(lib.qiddm_forward_shifted(ctypes.byref(cs), x.data_ptr(), batch, ld,
                                               table.data_ptr(), g.data_ptr(), g.shape[1], first, cnt,
-                                              dots.data_ptr(), _stream_ptr(device)))
+                                              dots.data_ptr(), ws_ptr, ws_bytes, _stream_ptr(device)))
         w_hi = min(first + cnt, 6 * n_rot)
         if first < w_hi:
             w_sum[first:w_hi] = dots[: w_hi - first].to(torch.float64).sum(dim=1)

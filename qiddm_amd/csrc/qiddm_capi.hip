@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "qsim_fused.h"
+#include "qsim_tiled.h"
 
 namespace {
 
@@ -27,9 +28,8 @@ int fail(int code, const char* fmt, ...) {
 int check_circuit(const qiddm_circuit_t* c) {
   if (!c) return fail(QIDDM_ERR_INVALID, "circ is NULL");
   if (c->n_qubits < 1) return fail(QIDDM_ERR_INVALID, "n_qubits=%d must be >= 1", c->n_qubits);
-  if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED)
-    return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d exceeds the fused-kernel limit %d", c->n_qubits,
-                QIDDM_MAX_QUBITS_FUSED);
+  if (c->n_qubits > QIDDM_MAX_QUBITS)
+    return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d exceeds the limit %d", c->n_qubits, QIDDM_MAX_QUBITS);
   if (c->encoding < QIDDM_ENC_NONE || c->encoding > QIDDM_ENC_RY)
     return fail(QIDDM_ERR_INVALID, "unknown encoding %d", c->encoding);
   if (c->imprimitive != QIDDM_IMP_CNOT && c->imprimitive != QIDDM_IMP_CZ)
@@ -203,6 +203,68 @@ int dispatch_dense(int n, const double* x, const double* wd, const double* bd, c
   }
 }
 
+// ---- n = 11..16: tiled kernel -----------------------------------------------------------------------
+int64_t tiled_blocks_x(int64_t batch, int64_t n_replicas) {
+  if (n_replicas <= 0) return batch < 512 ? batch : 512;
+  int64_t bx = 512 / n_replicas;
+  if (bx < 1) bx = 1;
+  if (bx > 64) bx = 64;
+  return batch < bx ? batch : bx;
+}
+
+int64_t tiled_workspace_bytes(const qiddm_circuit_t* c, int64_t batch, int64_t n_replicas) {
+  const int64_t slabs = tiled_blocks_x(batch, n_replicas) * (n_replicas > 0 ? n_replicas : 1);
+  const int64_t csize = c->dtype == QIDDM_F32 ? 8 : 16;
+  return 2 * slabs * ((int64_t)1 << c->n_qubits) * csize;  // ping-pong pair per workgroup
+}
+
+template <typename T, bool SHIFT>
+int launch_tiled(int n, const Ptrs& ptr, const qiddm::KScalars& p, int64_t n_replicas, void* ws,
+                 hipStream_t stream) {
+  if (p.batch == 0 || (SHIFT && n_replicas == 0)) return QIDDM_OK;
+  const int64_t n_rot = (int64_t)p.n_rounds * p.n_blocks * p.sel_layers * n;
+  const int64_t layers = (int64_t)p.n_blocks * p.sel_layers;
+  if (n_rot + 2 * layers + p.n_blocks + 2 * n > qiddm::kTiledMaxOps ||
+      2 * layers + 4 > qiddm::kTiledMaxPasses)
+    return fail(QIDDM_ERR_UNSUPPORTED, "circuit too deep for the tiled pass program (%lld layers)",
+                (long long)layers);
+  const size_t smem = qiddm::TiledSmem<T>::bytes(n_rot);
+  if (smem > kMaxLds)
+    return fail(QIDDM_ERR_UNSUPPORTED, "circuit with %lld Rot gates needs %zu B of LDS (limit %zu)",
+                (long long)n_rot, smem, kMaxLds);
+  auto kern = qiddm::tiled_circuit_kernel<T, SHIFT>;
+  static bool big_lds_enabled = false;
+  if (smem > 48 * 1024 && !big_lds_enabled) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    if (ea != hipSuccess)
+      return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
+    big_lds_enabled = true;
+  }
+  dim3 grid((unsigned)tiled_blocks_x(p.batch, SHIFT ? n_replicas : 0), SHIFT ? (unsigned)n_replicas : 1u, 1u);
+  qiddm::TiledScalars tp;
+  tp.n = n;
+  tp.pad_ = 0;
+  hipLaunchKernelGGL(kern, grid, dim3(qiddm::kTiledWaves * qiddm::kWave), smem, stream,
+                     static_cast<const T*>(ptr.inputs), static_cast<const T*>(ptr.table),
+                     static_cast<T*>(ptr.out), static_cast<const T*>(ptr.gout), static_cast<T*>(ptr.dots),
+                     static_cast<qiddm::V2<T>*>(ws), p, tp);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return fail(QIDDM_ERR_LAUNCH, "tiled_circuit_kernel<n=%d> launch failed: %s", n, hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
+int check_workspace(const qiddm_circuit_t* c, int64_t batch, int64_t n_replicas, const void* ws,
+                    int64_t ws_bytes) {
+  if (c->n_qubits <= QIDDM_MAX_QUBITS_FUSED) return QIDDM_OK;
+  const int64_t need = tiled_workspace_bytes(c, batch, n_replicas);
+  if (!ws || ws_bytes < need)
+    return fail(QIDDM_ERR_INVALID, "n_qubits=%d needs a %lld-byte workspace (got %lld)", c->n_qubits,
+                (long long)need, (long long)ws_bytes);
+  return QIDDM_OK;
+}
+
 qiddm::KScalars make_params(const qiddm_circuit_t* c) {
   qiddm::KScalars p;
   std::memset(&p, 0, sizeof(p));
@@ -228,7 +290,14 @@ int64_t out_cols(const qiddm_circuit_t* c) {
 extern "C" {
 
 int qiddm_abi_version(void) { return QIDDM_ABI_VERSION; }
-int qiddm_max_qubits(void) { return QIDDM_MAX_QUBITS_FUSED; }
+int qiddm_max_qubits(void) { return QIDDM_MAX_QUBITS; }
+
+int64_t qiddm_workspace_bytes(const qiddm_circuit_t* c, int64_t batch, int64_t n_replicas) {
+  if (check_circuit(c) != QIDDM_OK) return -1;
+  if (batch < 0 || n_replicas < 0) return -1;
+  if (c->n_qubits <= QIDDM_MAX_QUBITS_FUSED || batch == 0) return 0;
+  return tiled_workspace_bytes(c, batch, n_replicas);
+}
 const char* qiddm_last_error(void) { return g_err; }
 
 int64_t qiddm_num_rot_gates(const qiddm_circuit_t* c) {
@@ -283,7 +352,8 @@ int qiddm_prepare_gates(const qiddm_circuit_t* c, const double* angles, void* ga
 }
 
 int qiddm_forward(const qiddm_circuit_t* c, const void* inputs, int64_t batch, int64_t in_ld,
-                  const void* gate_table, void* out, int64_t out_ld, void* stream) {
+                  const void* gate_table, void* out, int64_t out_ld, void* workspace,
+                  int64_t workspace_bytes, void* stream) {
   int rc = check_circuit(c);
   if (rc != QIDDM_OK) return rc;
   if (batch < 0) return fail(QIDDM_ERR_INVALID, "batch=%lld < 0", (long long)batch);
@@ -306,13 +376,20 @@ int qiddm_forward(const qiddm_circuit_t* c, const void* inputs, int64_t batch, i
   p.out_ld = out_ld;
   p.batch = batch;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED) {
+    rc = check_workspace(c, batch, 0, workspace, workspace_bytes);
+    if (rc != QIDDM_OK) return rc;
+    return c->dtype == QIDDM_F32 ? launch_tiled<float, false>(c->n_qubits, ptr, p, 0, workspace, st)
+                                 : launch_tiled<double, false>(c->n_qubits, ptr, p, 0, workspace, st);
+  }
   return c->dtype == QIDDM_F32 ? dispatch_n<float, false>(c->n_qubits, ptr, p, 0, st)
                                : dispatch_n<double, false>(c->n_qubits, ptr, p, 0, st);
 }
 
 int qiddm_forward_shifted(const qiddm_circuit_t* c, const void* inputs, int64_t batch, int64_t in_ld,
                           const void* gate_table, const void* grad_out, int64_t g_ld,
-                          int64_t first_replica, int64_t n_replicas, void* dots, void* stream) {
+                          int64_t first_replica, int64_t n_replicas, void* dots, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
   int rc = check_circuit(c);
   if (rc != QIDDM_OK) return rc;
   if (c->n_rounds != 1)
@@ -348,6 +425,13 @@ int qiddm_forward_shifted(const qiddm_circuit_t* c, const void* inputs, int64_t 
   p.batch = batch;
   p.first_replica = (int32_t)first_replica;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED) {
+    rc = check_workspace(c, batch, n_replicas, workspace, workspace_bytes);
+    if (rc != QIDDM_OK) return rc;
+    return c->dtype == QIDDM_F32
+               ? launch_tiled<float, true>(c->n_qubits, ptr, p, n_replicas, workspace, st)
+               : launch_tiled<double, true>(c->n_qubits, ptr, p, n_replicas, workspace, st);
+  }
   return c->dtype == QIDDM_F32 ? dispatch_n<float, true>(c->n_qubits, ptr, p, n_replicas, st)
                                : dispatch_n<double, true>(c->n_qubits, ptr, p, n_replicas, st);
 }
@@ -361,6 +445,9 @@ int qiddm_dense_forward(const qiddm_circuit_t* c, const double* x, int64_t batch
   if (rc != QIDDM_OK) return rc;
   if (c->encoding != QIDDM_ENC_RZ || c->measure != QIDDM_MEAS_EXPZ)
     return fail(QIDDM_ERR_UNSUPPORTED, "dense forward needs the RZ encoding and the <Z> read-out");
+  if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED)
+    return fail(QIDDM_ERR_UNSUPPORTED, "dense forward is fused for n <= %d; use qiddm_forward for n=%d",
+                QIDDM_MAX_QUBITS_FUSED, c->n_qubits);
   if (batch < 0) return fail(QIDDM_ERR_INVALID, "batch=%lld < 0", (long long)batch);
   if (in_features < 1 || out_features < 1 || in_features > (1 << 24) || out_features > (1 << 24))
     return fail(QIDDM_ERR_INVALID, "bad feature counts %lld / %lld", (long long)in_features,

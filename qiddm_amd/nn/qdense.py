@@ -225,7 +225,7 @@ class QNN_noise(_QuantumNet):
     def forward(self, x):
         b, c, w, h = x.shape
         flat = x.reshape(b, -1).to(self.linear_down.weight.device).to(torch.double)
-        if self._fused_rounds_ok():
+        if self._fused_rounds_ok() and self.hidden_features <= 10:
             # inference: linear_down + circuit + linear_up in one launch
             circ = self._circuit_descriptor()
             out = _c.dense_forward(circ, flat, self.linear_down.weight, self.linear_down.bias,
@@ -418,7 +418,7 @@ class _QIDDMBase(_QuantumNet):
 
     def forward(self, x):
         b, c, w, h = x.shape
-        if self._fused_rounds_ok() and not self._use_pca:
+        if self._fused_rounds_ok() and not self._use_pca and self.hidden_features <= 10:
             # inference: linear_down + N chained rounds + linear_up in one launch
             circ = _c.Circuit(n_qubits=self.hidden_features, encoding="rz", imprimitive="CZ",
                               measure="expz", n_rounds=self.N, n_blocks=self.spectrum_layer, sel_layers=2)

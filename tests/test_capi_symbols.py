@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 def test_introspection_calls_need_no_gpu(hip_lib):
     assert hip_lib.qiddm_abi_version() == 1
-    assert hip_lib.qiddm_max_qubits() == 10
+    assert hip_lib.qiddm_max_qubits() == 16
     from qiddm_amd.circuit import Circuit
     # SURVEY section 8a gate counts
     cases = [
@@ -44,11 +44,17 @@ def test_introspection_calls_need_no_gpu(hip_lib):
     cs = cases[1][0].c_struct("f32")
     assert hip_lib.qiddm_num_shift_replicas(ctypes.byref(cs), 0) == 6 * 192
     assert hip_lib.qiddm_num_shift_replicas(ctypes.byref(cs), 1) == 6 * 192 + 2 * 6 * 8
+    # workspace: none for register-resident circuits, one slab per resident workgroup beyond n = 10
+    assert hip_lib.qiddm_workspace_bytes(ctypes.byref(cs), 4096, 0) == 0
+    c16 = Circuit(16, "rz", "CZ", "expz", 2, 6, 2).c_struct("f32")
+    assert hip_lib.qiddm_workspace_bytes(ctypes.byref(c16), 1024, 0) == 2 * 512 * (1 << 16) * 8
+    assert hip_lib.qiddm_workspace_bytes(ctypes.byref(c16), 3, 0) == 2 * 3 * (1 << 16) * 8
+    assert hip_lib.qiddm_gate_count(ctypes.byref(c16)) == 960
 
 
 def test_invalid_descriptors_are_rejected_with_a_reason(hip_lib):
     from qiddm_amd.circuit import Circuit
-    cs = Circuit(12, "rz").c_struct("f32")
+    cs = Circuit(17, "rz").c_struct("f32")
     assert hip_lib.qiddm_gate_count(ctypes.byref(cs)) == -1
     assert b"exceeds" in hip_lib.qiddm_last_error()
     cs = Circuit(2, "amplitude", "CNOT", "probs", n_features=5).c_struct("f32")

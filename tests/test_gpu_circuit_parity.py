@@ -169,9 +169,9 @@ def test_noncontiguous_and_wide_inputs():
 def test_errors_are_loud():
     from qiddm_amd._capi import QiddmError
     from qiddm_amd.circuit import Circuit, run_forward
-    w = torch.zeros(1, 1, 1, 12, 3, dtype=torch.float64).cuda()
-    with pytest.raises(QiddmError):
-        run_forward(Circuit(n_qubits=12, encoding="rz"), torch.zeros(2, 12).cuda(), w)
+    w = torch.zeros(1, 1, 1, 17, 3, dtype=torch.float64).cuda()
+    with pytest.raises(QiddmError, match="exceeds the limit 16"):
+        run_forward(Circuit(n_qubits=17, encoding="rz"), torch.zeros(2, 17).cuda(), w)
     with pytest.raises(ValueError, match="Features must be of length"):
         run_forward(Circuit(n_qubits=2, encoding="amplitude", imprimitive="CNOT", measure="probs"),
                     torch.zeros(2, 5).cuda(), torch.zeros(1, 1, 1, 2, 3, dtype=torch.float64).cuda())

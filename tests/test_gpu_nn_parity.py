@@ -239,3 +239,36 @@ def test_dense_forward_kernel(n, N, L, S, P, precision, tol):
     got2 = dense_forward(circ, dev(x), dev(wd), None, dev(w), dev(wu), None, precision).cpu()
     ref2 = oc.run_circuit(spec, x @ wd.T, w) @ wu.T
     assert torch.allclose(got2, ref2, atol=tol, rtol=tol)
+
+
+def test_c5_style_16_qubit_qdense():
+    """BASELINE config 5 shape: 28x28x3 = 2352 pixels, 16-qubit LL-style net (2352, 16, 6, 2):
+    linear glue on torch, circuit on the n > 10 tiled kernel."""
+    from qiddm_amd import nn
+    torch.manual_seed(21)
+    m = nn.QIDDM_LL_noise(2352, 16, 6, 2).to(DEV, dtype=torch.double)
+    x = torch.rand(3, 1, 28, 84, dtype=torch.float64)
+    with torch.no_grad():
+        got = m(x.to(DEV)).cpu()
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    ref = oc.qiddm_ll_forward(x, sd["linear_down.weight"], sd["linear_down.bias"], sd["weights1"],
+                              sd["linear_up.weight"], sd["linear_up.bias"])
+    assert got.shape == x.shape
+    assert torch.allclose(got, ref, atol=5e-5, rtol=1e-4), (got - ref).abs().max()
+
+
+def test_c4_style_12_qubit_qconv():
+    """BASELINE config 4 shape: QConv2d(C_in=256, C_out=256, k=3) -> 12 wires (nn/qconv.py:24-28)."""
+    import warnings
+    from qiddm_amd import nn
+    torch.manual_seed(22)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m = nn.QConv2d(256, 256, 3, 1, 3).to(DEV)
+    assert m.wires == 12
+    x = torch.rand(1, 256, 3, 3, dtype=torch.float64)
+    with torch.no_grad():
+        got = m(x.to(DEV)).cpu()
+    ref = oc.qconv2d_forward(x, m.weights.detach().cpu(), 256, (3, 3), (1, 1))
+    assert got.shape == (1, 256, 3, 3)
+    assert torch.allclose(got, ref, atol=1e-3), (got - ref).abs().max()
