@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--steps-per-graph", type=int, default=10,
                     help="consecutive denoise steps of the sampling loop captured per hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (non-headline) timings")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
     return ap.parse_args()
 
@@ -149,6 +150,63 @@ def time_dominant_kernel(net, x_dev, launches=200):
     torch.cuda.synchronize()
     avg_us = e0.elapsed_time(e1) * 1e3 / (reps * launches)
     return avg_us, circ
+
+
+def _time_fn(fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def secondary_measurements(dev, batch):
+    """Other members of the same path on the same (batch, 1, 28, 28) shape -- reported next to the
+    headline number, never instead of it: the re-uploading LL-style net, the
+    unet_simple net, and training steps of the flagship (B*tau samples through fwd + bwd + Adam)."""
+    from qiddm_amd import models, nn, noise
+    out = {}
+    x = (torch.rand(batch, 1, IMG, IMG, dtype=torch.double) * 0.75 + 0.5).to(dev)
+    try:
+        torch.manual_seed(42)
+        ll = nn.QIDDM_LL_noise(IMG * IMG, 8, 6, 2).to(dev, dtype=torch.double).eval()
+        with torch.no_grad():
+            t = _time_fn(lambda: ll(x), 50)
+        out["denoise_images_per_s_QIDDM_LL_noise(784,8,6,2)"] = batch / t
+        out["gate_apps_per_s_QIDDM_LL_noise(784,8,6,2)"] = batch * 480 / t
+    except Exception as e:  # pragma: no cover
+        out["ll_error"] = repr(e)
+    try:
+        torch.manual_seed(42)
+        unet = nn.UNetUndirectedS(3, 8, 3).to(dev, dtype=torch.double).eval()
+        xb = x
+        with torch.no_grad():
+            t = _time_fn(lambda: unet(xb), 5, warm=1)
+        out["denoise_images_per_s_UNetUndirectedS(3,8,3)"] = xb.shape[0] / t
+    except Exception as e:  # pragma: no cover
+        out["unet_error"] = repr(e)
+    for tag, detach in (("as_written_F1", True), ("parameter_shift", False)):
+        try:
+            torch.manual_seed(42)
+            net = nn.QNN_noise(IMG * IMG, N_QUBITS, QDEPTH, detach_quantum=detach)
+            diff = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (IMG, IMG),
+                                    torch.nn.MSELoss()).to(dev, dtype=torch.double).train()
+            opt = torch.optim.Adam(diff.parameters(), lr=1e-3)
+            xt = x.reshape(batch, -1)[: (batch if detach else min(batch, 32))]
+            tau = 10
+
+            def step():
+                opt.zero_grad()
+                diff(x=xt, T=tau)
+                opt.step()
+            t = _time_fn(step, 10 if detach else 2, warm=1)
+            out[f"train_images_per_s_{tag}"] = xt.shape[0] * tau / t
+        except Exception as e:  # pragma: no cover
+            out[f"train_error_{tag}"] = repr(e)
+    return out
 
 
 def cpu_baseline(diff, x0_cpu, budget_s):
@@ -258,6 +316,8 @@ def main():
                                  "lives in registers, so physical HBM traffic is images in/out + weights; "
                                  "the kernel also does linear_down/linear_up of the step"},
         }
+        if not args.no_secondary and world == 1:
+            result["secondary"] = secondary_measurements(dev, args.batch)
         if not args.no_cpu_baseline and world == 1:
             v, n_steps, el = cpu_baseline(diff, x0, args.cpu_seconds)
             result["cpu_baseline"] = {

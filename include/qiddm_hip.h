@@ -178,6 +178,22 @@ int qiddm_dense_forward(const qiddm_circuit_t *circ, const double *x, int64_t ba
                         int64_t out_features, int32_t post_mode, double noise_factor, double *y,
                         int64_t y_ld, void *stream);
 
+/* ---- fused quantum convolution -------------------------------------------------------
+ * Replaces the (intended, SURVEY finding F3) forward of the reference's exported QConv2d
+ * (`_QConv2d_FAST`, nn/qconv.py:51-87) in one launch:
+ *     torch.nn.Unfold(kernel, padding) -> + enc_offset (0.1) -> AmplitudeEmbedding(pad_with 0.5,
+ *     normalize) -> StronglyEntanglingLayers(angles, CNOT) -> probs -> * 2^n / 2 -> clamp [0,1] ->
+ *     [:, ::2][:, :out_channels] -> (batch, out_channels, H_out, W_out)
+ * x: (batch, in_channels, H, W) float64 contiguous; y: (batch, out_channels, H_out, W_out) float64
+ * with H_out = H + 2*pad_h - kh + 1.  circ: QIDDM_ENC_AMPLITUDE, QIDDM_MEAS_PROBS, n_rounds =
+ * n_blocks = 1, n_features = in_channels*kh*kw, n_qubits <= 10.  `angles` is the (1,1,S,n,3) float64
+ * tensor AFTER the qw_map.tanh map.  out_channels beyond 2^n / 2 do not exist (the reference's slice
+ * silently returns fewer channels): they are rejected here.                                  */
+int qiddm_qconv_forward(const qiddm_circuit_t *circ, const double *x, int64_t batch,
+                        int64_t in_channels, int64_t height, int64_t width, int64_t kh, int64_t kw,
+                        int64_t pad_h, int64_t pad_w, const double *angles, int64_t out_channels,
+                        double *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

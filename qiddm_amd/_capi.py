@@ -38,6 +38,7 @@ EXPORTS = (
     "qiddm_forward",
     "qiddm_forward_shifted",
     "qiddm_dense_forward",
+    "qiddm_qconv_forward",
 )
 
 
@@ -96,6 +97,8 @@ def _declare(lib):
     lib.qiddm_dense_forward.restype = ctypes.c_int
     lib.qiddm_dense_forward.argtypes = [P, vp, i64, i64, i64, vp, vp, vp, vp, vp, i64, ctypes.c_int32,
                                         ctypes.c_double, vp, i64, vp]
+    lib.qiddm_qconv_forward.restype = ctypes.c_int
+    lib.qiddm_qconv_forward.argtypes = [P, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, vp, vp]
 
 
 def _preload_torch_hip_runtime():

@@ -231,6 +231,32 @@ def dense_forward(circ: Circuit, x: torch.Tensor, w_down, b_down, angles, w_up, 
     return y
 
 
+def qconv_forward(x: torch.Tensor, angles: torch.Tensor, n_qubits: int, out_channels: int, kernel_size,
+                  padding, precision: str | None = None) -> torch.Tensor:
+    """The intended QConv2d forward in one launch (``qiddm_qconv_forward``); no autograd.
+    x: (B, C, H, W) -> (B, out_channels, H_out, W_out) float64.  angles: (S, n, 3) after the
+    pi*tanh map."""
+    precision = precision or _default_precision
+    _require_device(angles, "the circuit weights")
+    _require_device(x, "the input batch")
+    device = angles.device
+    b, c, h, w = x.shape
+    kh, kw = kernel_size
+    ph, pw = padding
+    circ = Circuit(n_qubits=n_qubits, encoding="amplitude", imprimitive="CNOT", measure="probs",
+                   n_rounds=1, n_blocks=1, sel_layers=angles.shape[0], n_features=c * kh * kw,
+                   enc_offset=0.1, pad_with=0.5)
+    xx = _as_f64(x, device)
+    ang = _as_f64(angles, device)
+    ho, wo = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+    y = torch.empty(b, out_channels, ho, wo, dtype=torch.float64, device=device)
+    cs = circ.c_struct(precision)
+    _capi.check(_capi.lib().qiddm_qconv_forward(ctypes.byref(cs), xx.data_ptr(), b, c, h, w, kh, kw, ph, pw,
+                                                ang.data_ptr(), out_channels, y.data_ptr(),
+                                                _stream_ptr(device)))
+    return y
+
+
 def run_shift_sweep(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch.Tensor,
                     precision: str | None = None, with_inputs: bool = True,
                     max_dots_elems: int = 1 << 26):

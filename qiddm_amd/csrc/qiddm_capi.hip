@@ -203,6 +203,55 @@ int dispatch_dense(int n, const double* x, const double* wd, const double* bd, c
   }
 }
 
+template <typename T, int N>
+int launch_qconv(const double* x, const double* angles, double* y, const qiddm::ConvScalars& cv,
+                 const qiddm::KScalars& p, hipStream_t stream) {
+  using L = qiddm::Layout<N>;
+  using S = qiddm::Smem<T, N>;
+  const int64_t groups = (p.batch + L::SPW - 1) / L::SPW;
+  if (groups == 0) return QIDDM_OK;
+  const int waves = 4;
+  int64_t bx = (groups + waves - 1) / waves;
+  if (bx > 4096) bx = 4096;
+  const int64_t n_rot = (int64_t)p.sel_layers * N;
+  const size_t smem = S::bytes(n_rot, p.imprimitive == QIDDM_IMP_CNOT, waves);
+  if (smem > kMaxLds)
+    return fail(QIDDM_ERR_UNSUPPORTED, "circuit with %lld Rot gates needs %zu B of LDS (limit %zu)",
+                (long long)n_rot, smem, kMaxLds);
+  auto kern = qiddm::qconv_forward_kernel<T, N>;
+  static bool big_lds_enabled = false;
+  if (smem > 48 * 1024 && !big_lds_enabled) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    if (ea != hipSuccess)
+      return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
+    big_lds_enabled = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)bx), dim3(waves * qiddm::kWave), smem, stream, x, angles, y, cv, p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return fail(QIDDM_ERR_LAUNCH, "qconv_forward_kernel<n=%d> launch failed: %s", N, hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
+template <typename T>
+int dispatch_qconv(int n, const double* x, const double* angles, double* y, const qiddm::ConvScalars& cv,
+                   const qiddm::KScalars& p, hipStream_t st) {
+  switch (n) {
+    case 1: return launch_qconv<T, 1>(x, angles, y, cv, p, st);
+    case 2: return launch_qconv<T, 2>(x, angles, y, cv, p, st);
+    case 3: return launch_qconv<T, 3>(x, angles, y, cv, p, st);
+    case 4: return launch_qconv<T, 4>(x, angles, y, cv, p, st);
+    case 5: return launch_qconv<T, 5>(x, angles, y, cv, p, st);
+    case 6: return launch_qconv<T, 6>(x, angles, y, cv, p, st);
+    case 7: return launch_qconv<T, 7>(x, angles, y, cv, p, st);
+    case 8: return launch_qconv<T, 8>(x, angles, y, cv, p, st);
+    case 9: return launch_qconv<T, 9>(x, angles, y, cv, p, st);
+    case 10: return launch_qconv<T, 10>(x, angles, y, cv, p, st);
+    default: return fail(QIDDM_ERR_UNSUPPORTED, "fused QConv2d needs n_qubits <= 10 (got %d)", n);
+  }
+}
+
 // ---- n = 11..16: tiled kernel -----------------------------------------------------------------------
 int64_t tiled_blocks_x(int64_t batch, int64_t n_replicas) {
   if (n_replicas <= 0) return batch < 512 ? batch : 512;
@@ -476,6 +525,50 @@ int qiddm_dense_forward(const qiddm_circuit_t* c, const double* x, int64_t batch
   return c->dtype == QIDDM_F32
              ? dispatch_dense<float>(c->n_qubits, x, w_down, b_down, angles, w_up, b_up, y, d, p, st)
              : dispatch_dense<double>(c->n_qubits, x, w_down, b_down, angles, w_up, b_up, y, d, p, st);
+}
+
+int qiddm_qconv_forward(const qiddm_circuit_t* c, const double* x, int64_t batch, int64_t in_channels,
+                        int64_t height, int64_t width, int64_t kh, int64_t kw, int64_t pad_h,
+                        int64_t pad_w, const double* angles, int64_t out_channels, double* y,
+                        void* stream) {
+  int rc = check_circuit(c);
+  if (rc != QIDDM_OK) return rc;
+  if (c->encoding != QIDDM_ENC_AMPLITUDE || c->measure != QIDDM_MEAS_PROBS || c->n_rounds != 1 ||
+      c->n_blocks != 1)
+    return fail(QIDDM_ERR_UNSUPPORTED, "QConv2d needs amplitude encoding, probs, one round, one block");
+  if (batch < 0 || in_channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad_h < 0 || pad_w < 0 ||
+      out_channels < 1)
+    return fail(QIDDM_ERR_INVALID, "bad convolution geometry");
+  if (in_channels * kh * kw != c->n_features)
+    return fail(QIDDM_ERR_INVALID, "n_features=%d != in_channels*kh*kw=%lld", c->n_features,
+                (long long)(in_channels * kh * kw));
+  const int64_t ho = height + 2 * pad_h - kh + 1, wo = width + 2 * pad_w - kw + 1;
+  if (ho < 1 || wo < 1) return fail(QIDDM_ERR_INVALID, "kernel larger than the padded image");
+  const int64_t d = (int64_t)1 << c->n_qubits;
+  if (2 * out_channels > d && !(d == 2 && out_channels == 1))
+    return fail(QIDDM_ERR_INVALID, "out_channels=%lld exceeds the %lld even-index probabilities",
+                (long long)out_channels, (long long)(d / 2));
+  if (batch * ho * wo >= ((int64_t)1 << 40)) return fail(QIDDM_ERR_INVALID, "too many output pixels");
+  if (batch == 0) return QIDDM_OK;
+  if (!x || !angles || !y) return fail(QIDDM_ERR_INVALID, "x/angles/y is NULL");
+  qiddm::KScalars p = make_params(c);
+  p.batch = batch * ho * wo;  // one circuit per output pixel
+  qiddm::ConvScalars cv;
+  std::memset(&cv, 0, sizeof(cv));
+  cv.C = (int32_t)in_channels;
+  cv.H = (int32_t)height;
+  cv.W = (int32_t)width;
+  cv.kh = (int32_t)kh;
+  cv.kw = (int32_t)kw;
+  cv.ph = (int32_t)pad_h;
+  cv.pw = (int32_t)pad_w;
+  cv.Ho = (int32_t)ho;
+  cv.Wo = (int32_t)wo;
+  cv.C_out = (int32_t)out_channels;
+  cv.post_scale = 0.5 * (double)d;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return c->dtype == QIDDM_F32 ? dispatch_qconv<float>(c->n_qubits, x, angles, y, cv, p, st)
+                               : dispatch_qconv<double>(c->n_qubits, x, angles, y, cv, p, st);
 }
 
 }  // extern "C"

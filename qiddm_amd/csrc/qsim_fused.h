@@ -560,7 +560,8 @@ struct Engine {
   // xs: input angles (already scaled) for RZ/RY encodings; amp_row: feature row for
   // amplitude embedding.  On return pr[] holds the probabilities of this lane's
   // amplitudes and, for the <Z> read-out, result[] the n expectation values.
-  __device__ __forceinline__ void run(const KScalars& p, const T* __restrict__ amp_row, T (&xs)[N],
+  template <typename Src>
+  __device__ __forceinline__ void run(const KScalars& p, const Src& amp_src, T (&xs)[N],
                                       const Shift& sh, T (&result)[N], T (&pr)[R]) const {
     const bool use_cnot = p.imprimitive == 0;
     C a[R];
@@ -577,7 +578,7 @@ struct Engine {
         for (int r = 0; r < R; ++r) {
           const int k = (r << LB) | sub;
           T v = (T)p.pad_with;
-          if (k < p.n_features) v = amp_row[k] + (T)p.enc_offset;
+          if (k < p.n_features) v = amp_src(k) + (T)p.enc_offset;
           a[r] = C{v, (T)0};
           n2 += v * v;
         }
@@ -657,6 +658,30 @@ struct Engine {
   }
 };
 
+// feature sources for the amplitude embedding
+template <typename T>
+struct RowSrc {  // a row of a (batch, features) matrix
+  const T* __restrict__ row;
+  __device__ __forceinline__ T operator()(int k) const { return row[k]; }
+};
+struct NoSrc {
+  __device__ __forceinline__ float operator()(int) const { return 0.f; }
+};
+// torch.nn.Unfold on the fly: feature f = (c * kh + di) * kw + dj of the patch around output pixel
+// (oi, oj), zero padding outside the image (reference nn/qconv.py:23, 76)
+template <typename T>
+struct PatchSrc {
+  const double* __restrict__ img;  // (C, H, W) of this sample
+  int H, W, kh, kw, oi, oj;        // oi/oj already shifted by -padding
+  __device__ __forceinline__ T operator()(int f) const {
+    const int dj = f % kw, t = f / kw;
+    const int di = t % kh, c = t / kh;
+    const int i = oi + di, j = oj + dj;
+    if (i < 0 || i >= H || j < 0 || j >= W) return (T)0;
+    return (T)img[((size_t)c * H + i) * W + j];
+  }
+};
+
 // ---------------------------------------------------------------------------
 // circuit kernel: inputs -> probabilities / <Z>   (SHIFT: -> dot with upstream grad)
 // ---------------------------------------------------------------------------
@@ -713,7 +738,7 @@ __global__ __launch_bounds__(4 * kWave) void circuit_kernel(const T* __restrict_
       for (int j = 0; j < N; ++j) xs[j] = (T)0;
     }
     T result[N], pr[R];
-    eng.run(p, inputs + sample * p.in_ld, xs, sh, result, pr);
+    eng.run(p, RowSrc<T>{inputs + sample * p.in_ld}, xs, sh, result, pr);
 
     if constexpr (!SHIFT) {
       if (p.measure == 0) {
@@ -832,7 +857,7 @@ __global__ __launch_bounds__(WPB * kWave) void dense_forward_kernel(
     if (stamp) d.stamps[2] = __builtin_amdgcn_s_memtime();
     // ---- the circuit --------------------------------------------------------------------------
     T result[N], pr[R];
-    eng.run(p, nullptr, xs, no_shift, result, pr);
+    eng.run(p, NoSrc{}, xs, no_shift, result, pr);
     double ev[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) ev[j] = (double)result[j];
@@ -868,6 +893,68 @@ __global__ __launch_bounds__(WPB * kWave) void dense_forward_kernel(
       }
     }
     if (stamp) d.stamps[4] = __builtin_amdgcn_s_memtime();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// quantum convolution in one launch: unfold (+0.1) -> AmplitudeEmbedding(pad 0.5) -> SEL(CNOT) ->
+// probs -> * D/2, clamp, [::2], [:C_out] -> (B, C_out, H_out, W_out)   (the intended
+// _QConv2d_FAST.forward, reference nn/qconv.py:51-87, finding F3).  One circuit per output pixel,
+// one wavefront (or a slice of one) per circuit; neither the unfolded patches nor the
+// probability rows ever exist in HBM.
+// ---------------------------------------------------------------------------
+struct ConvScalars {
+  int32_t C, H, W, kh, kw, ph, pw, Ho, Wo, C_out;
+  double post_scale;  // D / 2
+};
+
+template <typename T, int N>
+__global__ __launch_bounds__(4 * kWave) void qconv_forward_kernel(const double* __restrict__ x,
+                                                                  const double* __restrict__ angles,
+                                                                  double* __restrict__ y,
+                                                                  const ConvScalars cv, const KScalars p) {
+  using E = Engine<T, N>;
+  using L = typename E::L;
+  constexpr int LB = L::LB, R = L::R, SPW = L::SPW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int n_rot = p.n_rounds * p.n_blocks * p.sel_layers * N;
+  E eng;
+  eng.carve(smem_raw, n_rot);
+  eng.fill_gates_from_angles(angles, n_rot);
+  eng.fill_rings(p.imprimitive == 0);
+  __syncthreads();
+  const int sub = eng.sub;
+  const int wave = threadIdx.x >> 6;
+  const int swave = eng.llane >> LB;
+  const typename E::Shift no_shift;
+  const int64_t pixels = (int64_t)cv.Ho * cv.Wo;
+  const int waves_per_block = blockDim.x >> 6;
+  const int64_t groups = (p.batch + SPW - 1) / SPW;
+  for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < groups;
+       grp += (int64_t)gridDim.x * waves_per_block) {
+    const int64_t m_raw = grp * SPW + swave;
+    const bool valid = m_raw < p.batch;
+    const int64_t m = valid ? m_raw : p.batch - 1;
+    const int64_t b = m / pixels;
+    const int pix = (int)(m - b * pixels);
+    const int oi = pix / cv.Wo, oj = pix - oi * cv.Wo;
+    const PatchSrc<T> src{x + (size_t)b * cv.C * cv.H * cv.W, cv.H, cv.W, cv.kh, cv.kw, oi - cv.ph, oj - cv.pw};
+    T xs[N], result[N], pr[R];
+#pragma unroll
+    for (int j = 0; j < N; ++j) xs[j] = (T)0;
+    eng.run(p, src, xs, no_shift, result, pr);
+    if (valid) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int k = (r << LB) | sub;
+        const int co = k >> 1;
+        if ((k & 1) == 0 && co < cv.C_out) {
+          double v = (double)pr[r] * cv.post_scale;
+          v = fmin(fmax(v, 0.0), 1.0);
+          y[(((size_t)b * cv.C_out + co) * cv.Ho + oi) * cv.Wo + oj] = v;
+        }
+      }
+    }
   }
 }
 

@@ -19,6 +19,7 @@ import warnings
 
 import torch
 
+from .. import circuit as _c
 from .. import qml
 from .qdense import _qw_tanh
 
@@ -44,6 +45,7 @@ class QConv2d(torch.nn.Module):
                                interface="torch", diff_method="backprop")
         self.sample_qnode = None
         self.sample_matrix = None
+        self._own_qnode = self.qnode
 
     def _circuit(self, features):
         qml.AmplitudeEmbedding(features=features.double(), wires=range(self.wires), pad_with=0.5,
@@ -60,6 +62,11 @@ class QConv2d(torch.nn.Module):
         assert c == self.in_channels, f"Expected {self.in_channels} channels, got {c}"
         h_out = h_in + 2 * self.padding[0] - self.kernel_size[0] + 1
         w_out = w_in + 2 * self.padding[1] - self.kernel_size[1] + 1
+        if (not torch.is_grad_enabled() and self.qnode is self._own_qnode and self.wires <= 10
+                and 2 * self.out_channels <= 2 ** self.wires):
+            # inference: unfold + embedding + circuit + post-processing in one launch
+            return _c.qconv_forward(x, _qw_tanh(self.weights.detach().double()), self.wires,
+                                    self.out_channels, self.kernel_size, self.padding)
         cols = self.unfold(x.double())                                   # (b, C k^2, h_out*w_out)
         feats = cols.transpose(1, 2).reshape(b * h_out * w_out, -1) + 0.1
         y = self._post_process(self.qnode(feats))                        # ((b h w), C_out)

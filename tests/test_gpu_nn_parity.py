@@ -272,3 +272,22 @@ def test_c4_style_12_qubit_qconv():
     ref = oc.qconv2d_forward(x, m.weights.detach().cpu(), 256, (3, 3), (1, 1))
     assert got.shape == (1, 256, 3, 3)
     assert torch.allclose(got, ref, atol=1e-3), (got - ref).abs().max()
+
+
+@pytest.mark.parametrize("cin,cout,k,pad,hw", [(1, 8, 3, 1, 9), (8, 16, 3, 1, 6), (32, 16, 1, 0, 7), (16, 8, 3, 1, 11),
+                                               (2, 2, (2, 3), (1, 0), 6)])
+def test_qconv2d_fused_equals_traced_path(cin, cout, k, pad, hw):
+    """qiddm_qconv_forward (unfold fused, inference) == unfold + QNode path == oracle."""
+    from qiddm_amd import nn
+    torch.manual_seed(31)
+    m = nn.QConv2d(cin, cout, k, pad, 2).to(DEV)
+    x = _img(2, hw, 3, c=cin)
+    with torch.no_grad():
+        fused = m(x.to(DEV)).cpu()
+    traced = m(x.to(DEV)).detach().cpu()          # grad enabled -> unfold + traced QNode
+    kk = k if isinstance(k, tuple) else (k, k)
+    pp = pad if isinstance(pad, tuple) else (pad, pad)
+    ref = oc.qconv2d_forward(x, m.weights.detach().cpu(), cout, kk, pp)
+    assert fused.shape == traced.shape == ref.shape
+    assert torch.allclose(fused, ref, atol=1e-3), (fused - ref).abs().max()
+    assert torch.allclose(fused, traced, atol=1e-4), (fused - traced).abs().max()
