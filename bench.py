@@ -188,21 +188,23 @@ def secondary_measurements(dev, batch):
         out["denoise_images_per_s_UNetUndirectedS(3,8,3)"] = xb.shape[0] / t
     except Exception as e:  # pragma: no cover
         out["unet_error"] = repr(e)
-    for tag, detach in (("as_written_F1", True), ("parameter_shift", False)):
+    for tag, detach in (("as_written_F1", True), ("parameter_shift", False), ("adjoint", False)):
         try:
             torch.manual_seed(42)
             net = nn.QNN_noise(IMG * IMG, N_QUBITS, QDEPTH, detach_quantum=detach)
+            if tag == "adjoint":
+                net.qnode.diff_method = "adjoint"     # the attribute the reference scripts poke
             diff = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (IMG, IMG),
                                     torch.nn.MSELoss()).to(dev, dtype=torch.double).train()
             opt = torch.optim.Adam(diff.parameters(), lr=1e-3)
-            xt = x.reshape(batch, -1)[: (batch if detach else min(batch, 32))]
+            xt = x.reshape(batch, -1)[: (batch if tag != "parameter_shift" else min(batch, 32))]
             tau = 10
 
             def step():
                 opt.zero_grad()
                 diff(x=xt, T=tau)
                 opt.step()
-            t = _time_fn(step, 10 if detach else 2, warm=1)
+            t = _time_fn(step, 10 if tag != "parameter_shift" else 2, warm=1)
             out[f"train_images_per_s_{tag}"] = xt.shape[0] * tau / t
         except Exception as e:  # pragma: no cover
             out[f"train_error_{tag}"] = repr(e)

@@ -157,6 +157,23 @@ int qiddm_forward_shifted(const qiddm_circuit_t *circ, const void *inputs, int64
                           int64_t g_ld, int64_t first_replica, int64_t n_replicas, void *dots,
                           void *workspace, int64_t workspace_bytes, void *stream);
 
+/* ---- adjoint (reverse-mode) backward ----------------------------------------------------
+ * Replaces what diff_method="backprop" computes in the reference (torch autograd through
+ * default.qubit.torch, nn/qdense.py:37, 419; nn/qconv.py:46) for ONE QNode round (n_rounds == 1,
+ * n_qubits <= 10):  given grad_out = dL/d(out) of qiddm_forward it returns
+ *   k_partials : (n_partials, n_rot, 8) of circ->dtype -- per-workgroup partial sums over the batch of
+ *                K_{ab} = sum conj(lambda_a) psi_b for every Rot gate (a,b in {0,1}, as re/im pairs in the
+ *                order K00 K01 K10 K11); the caller sums them over dim 0 and contracts with the analytic
+ *                dRot/d(phi,theta,omega):  dL/dangle = 2 Re sum_ab (dU/dangle)_ab K_ab.
+ *                n_partials = qiddm_adjoint_partials(circ, batch).
+ *   grad_inputs: (batch, gin_ld) dL/d(inputs): n columns for RZ / RY encodings, n_features columns for
+ *                the amplitude embedding (gradient through pad + normalise); may be NULL.
+ * Cost: about five forward passes, independent of the number of parameters.                     */
+int64_t qiddm_adjoint_partials(const qiddm_circuit_t *circ, int64_t batch);
+int qiddm_backward_adjoint(const qiddm_circuit_t *circ, const void *inputs, int64_t batch,
+                           int64_t in_ld, const void *gate_table, const void *grad_out, int64_t g_ld,
+                           void *k_partials, void *grad_inputs, int64_t gin_ld, void *stream);
+
 /* ---- fused dense-net forward ------------------------------------------------------
  * Replaces the whole forward of the reference's linear_down -> quantum rounds -> linear_up
  * nets in one launch: QNN_noise.forward / QNN.forward (reference nn/qdense.py:267-289,

@@ -59,7 +59,7 @@ def run_round(spec: Spec, inputs, weights):
         if spec.encoding == "rz":
             st = sv.angle_embedding_rz(st, x, n, scale=spec.enc_scale)
         elif spec.encoding == "ry" and (blk == 0 or not spec.ry_once):
-            st = sv.angle_embedding_ry(st, x, n)
+            st = sv.angle_embedding_ry(st, x * spec.enc_scale, n)
         st = sv.strongly_entangling_layers(st, w[blk], n, spec.imprimitive)
     if spec.measure == "probs":
         return sv.probs(st)

@@ -37,6 +37,8 @@ EXPORTS = (
     "qiddm_prepare_gates",
     "qiddm_forward",
     "qiddm_forward_shifted",
+    "qiddm_adjoint_partials",
+    "qiddm_backward_adjoint",
     "qiddm_dense_forward",
     "qiddm_qconv_forward",
 )
@@ -97,6 +99,10 @@ def _declare(lib):
     lib.qiddm_dense_forward.restype = ctypes.c_int
     lib.qiddm_dense_forward.argtypes = [P, vp, i64, i64, i64, vp, vp, vp, vp, vp, i64, ctypes.c_int32,
                                         ctypes.c_double, vp, i64, vp]
+    lib.qiddm_adjoint_partials.restype = i64
+    lib.qiddm_adjoint_partials.argtypes = [P, i64]
+    lib.qiddm_backward_adjoint.restype = ctypes.c_int
+    lib.qiddm_backward_adjoint.argtypes = [P, vp, i64, i64, vp, vp, i64, vp, vp, i64, vp]
     lib.qiddm_qconv_forward.restype = ctypes.c_int
     lib.qiddm_qconv_forward.argtypes = [P, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, vp, vp]
 

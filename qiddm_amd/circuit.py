@@ -303,15 +303,65 @@ def run_shift_sweep(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch
     return grad_angles, grad_inputs
 
 
+def _rot_matrices(angles: torch.Tensor) -> torch.Tensor:
+    """(G, 3) float64 (phi, theta, omega) -> (G, 2, 2) complex128 RZ(omega) RY(theta) RZ(phi),
+    differentiable (used to contract the adjoint kernel's K matrices with dRot/dangle)."""
+    phi, theta, omega = angles[:, 0], angles[:, 1], angles[:, 2]
+    c, s = torch.cos(0.5 * theta), torch.sin(0.5 * theta)
+    a, b = 0.5 * (phi + omega), 0.5 * (phi - omega)
+    ea = torch.complex(torch.cos(a), torch.sin(a))
+    eb = torch.complex(torch.cos(b), torch.sin(b))
+    row0 = torch.stack([ea.conj() * c, -eb * s], dim=-1)
+    row1 = torch.stack([eb.conj() * s, ea * c], dim=-1)
+    return torch.stack([row0, row1], dim=-2)
+
+
+def run_adjoint(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch.Tensor,
+                precision: str | None = None, with_inputs: bool = True):
+    """Reverse-mode gradients of one QNode round (``qiddm_backward_adjoint``).
+    Returns (grad_angles (angles_shape, f64), grad_inputs (B, n | n_features) f64 or None)."""
+    precision = precision or _default_precision
+    dtype = _DT[precision][1]
+    device = angles.device
+    if circ.n_rounds != 1:
+        raise ValueError("run_adjoint differentiates one round")
+    x, ld, circ2 = _prep_inputs(circ, inputs, dtype, device)
+    circ = circ2 or circ
+    batch = x.shape[0]
+    lib = _capi.lib()
+    cs = circ.c_struct(precision)
+    table = prepare_gates(circ, angles, precision)
+    g = grad_out.to(device=device, dtype=dtype).contiguous()
+    n_rot = lib.qiddm_num_rot_gates(ctypes.byref(cs))
+    n_part = lib.qiddm_adjoint_partials(ctypes.byref(cs), batch)
+    if n_part < 0:
+        _capi.check(-2)
+    kp = torch.empty(n_part, n_rot, 8, dtype=dtype, device=device)
+    gin = None
+    gin_cols = circ.features if circ.encoding == "amplitude" else circ.n_qubits
+    if with_inputs and circ.encoding != "none":
+        gin = torch.empty(batch, gin_cols, dtype=dtype, device=device)
+    _capi.check(lib.qiddm_backward_adjoint(ctypes.byref(cs), x.data_ptr(), batch, ld, table.data_ptr(),
+                                           g.data_ptr(), g.shape[1], kp.data_ptr(),
+                                           0 if gin is None else gin.data_ptr(), gin_cols, _stream_ptr(device)))
+    k = kp.to(torch.float64).sum(dim=0)                                   # (G, 8)
+    kc = torch.complex(k[:, 0::2], k[:, 1::2]).reshape(n_rot, 2, 2)       # K_ab
+    with torch.enable_grad():
+        a = angles.detach().to(torch.float64).reshape(-1, 3).clone().requires_grad_(True)
+        proxy = 2.0 * (_rot_matrices(a) * kc).sum().real
+        (ga,) = torch.autograd.grad(proxy, a)
+    return ga.reshape(circ.angles_shape), (None if gin is None else gin.to(torch.float64))
+
+
 class _QNodeFunction(torch.autograd.Function):
     """One QNode round, differentiable by parameter shift (2 evaluations per
     gate angle, coefficient 1/2 -- the rule PennyLane applies for
     diff_method="parameter-shift", configured at reference nn/qdense.py:246)."""
 
     @staticmethod
-    def forward(ctx, inputs, angles, circ, precision):
+    def forward(ctx, inputs, angles, circ, precision, diff_method):
         out = run_forward(circ, inputs, angles, precision)
-        ctx.circ, ctx.precision = circ, precision
+        ctx.circ, ctx.precision, ctx.diff_method = circ, precision, diff_method
         ctx.save_for_backward(inputs if inputs is not None else torch.empty(0), angles)
         ctx.in_shape = None if inputs is None else tuple(inputs.shape)
         return out
@@ -321,24 +371,31 @@ class _QNodeFunction(torch.autograd.Function):
         inputs, angles = ctx.saved_tensors
         circ = ctx.circ
         need_in = ctx.needs_input_grad[0]
-        if need_in and circ.encoding == "amplitude":
+        use_adjoint = ctx.diff_method != "parameter-shift" and circ.n_qubits <= 10
+        if need_in and circ.encoding == "amplitude" and not use_adjoint:
             raise NotImplementedError(
                 "gradient w.r.t. amplitude-embedded features is not a gate parameter; "
-                "parameter-shift cannot provide it")
-        ga, gi = run_shift_sweep(circ, inputs, angles, grad_out, ctx.precision, with_inputs=need_in)
+                "parameter-shift cannot provide it (use diff_method='backprop', n <= 10)")
+        if use_adjoint:
+            ga, gi = run_adjoint(circ, inputs, angles, grad_out, ctx.precision, with_inputs=need_in)
+        else:
+            ga, gi = run_shift_sweep(circ, inputs, angles, grad_out, ctx.precision, with_inputs=need_in)
         grad_inputs = None
         if need_in and gi is not None:
             full = torch.zeros(inputs.shape if inputs.dim() == 2 else (1,) + tuple(inputs.shape),
                                dtype=inputs.dtype, device=inputs.device)
-            full[:, : circ.n_qubits] = gi.to(inputs.dtype)
+            full[:, : gi.shape[1]] = gi.to(inputs.dtype)
             grad_inputs = full.view(ctx.in_shape)
-        return grad_inputs, ga.to(angles.dtype), None, None
+        return grad_inputs, ga.to(angles.dtype), None, None, None
 
 
-def execute(circ: Circuit, inputs, angles: torch.Tensor, precision: str | None = None) -> torch.Tensor:
+def execute(circ: Circuit, inputs, angles: torch.Tensor, precision: str | None = None,
+            diff_method: str = "backprop") -> torch.Tensor:
     """Differentiable execution of ``circ`` (all rounds).  With grad enabled the
     rounds run one QNode call at a time, as the reference chains them
-    (nn/qdense.py:464-465); under ``torch.no_grad()`` they are fused in one launch."""
+    (nn/qdense.py:464-465); under ``torch.no_grad()`` they are fused in one launch.
+    diff_method "parameter-shift": 2 kernel re-invocations per gate angle; anything else
+    ("backprop", "adjoint", "best"): the adjoint kernel (n <= 10; parameter shift beyond)."""
     precision = precision or _default_precision
     _require_device(angles, "the circuit weights")
     needs_grad = torch.is_grad_enabled() and (
@@ -349,6 +406,6 @@ def execute(circ: Circuit, inputs, angles: torch.Tensor, precision: str | None =
     out = None
     one = replace(circ, n_rounds=1)
     for r in range(circ.n_rounds):
-        out = _QNodeFunction.apply(x, angles[r:r + 1], one, precision)
+        out = _QNodeFunction.apply(x, angles[r:r + 1], one, precision, diff_method)
         x = out
     return out

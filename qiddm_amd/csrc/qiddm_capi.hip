@@ -12,6 +12,7 @@
 
 #include "qsim_fused.h"
 #include "qsim_tiled.h"
+#include "qsim_adjoint.h"
 
 namespace {
 
@@ -252,6 +253,75 @@ int dispatch_qconv(int n, const double* x, const double* angles, double* y, cons
   }
 }
 
+// ---- adjoint backward (n <= 10) -------------------------------------------------------------------------
+template <int N>
+int64_t adjoint_blocks(int64_t batch) {
+  using L = qiddm::Layout<N>;
+  const int64_t groups = (batch + L::SPW - 1) / L::SPW;
+  int64_t bx = (groups + 3) / 4;
+  if (bx > 512) bx = 512;
+  return bx < 1 ? 1 : bx;
+}
+int64_t adjoint_blocks_n(int n, int64_t batch) {
+  switch (n) {
+    case 1: return adjoint_blocks<1>(batch);
+    case 2: return adjoint_blocks<2>(batch);
+    case 3: return adjoint_blocks<3>(batch);
+    case 4: return adjoint_blocks<4>(batch);
+    case 5: return adjoint_blocks<5>(batch);
+    default: return adjoint_blocks<6>(batch);  // SPW == 1 from n = 6 on
+  }
+}
+
+template <typename T, int N>
+int launch_adjoint(const Ptrs& ptr, T* k_partials, T* grad_inputs, const qiddm::KScalars& p,
+                   const qiddm::AdjointScalars& ad, hipStream_t stream) {
+  using S = qiddm::Smem<T, N>;
+  const int waves = 4;
+  const int64_t n_rot = (int64_t)p.n_blocks * p.sel_layers * N;
+  const size_t smem = S::bytes(n_rot, p.imprimitive == QIDDM_IMP_CNOT, waves) +
+                      (size_t)n_rot * qiddm::kLdsGateReals * sizeof(T) + (size_t)waves * n_rot * 8 * sizeof(T);
+  if (smem > kMaxLds)
+    return fail(QIDDM_ERR_UNSUPPORTED, "circuit with %lld Rot gates needs %zu B of LDS for the adjoint pass",
+                (long long)n_rot, smem);
+  auto kern = qiddm::adjoint_kernel<T, N>;
+  static bool big_lds_enabled = false;
+  if (smem > 48 * 1024 && !big_lds_enabled) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    if (ea != hipSuccess)
+      return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
+    big_lds_enabled = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)adjoint_blocks<N>(p.batch)), dim3(waves * qiddm::kWave), smem, stream,
+                     static_cast<const T*>(ptr.inputs), static_cast<const T*>(ptr.table),
+                     static_cast<const T*>(ptr.gout), k_partials, grad_inputs, p, ad);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return fail(QIDDM_ERR_LAUNCH, "adjoint_kernel<n=%d> launch failed: %s", N, hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
+template <typename T>
+int dispatch_adjoint(int n, const Ptrs& ptr, void* kp, void* gi, const qiddm::KScalars& p,
+                     const qiddm::AdjointScalars& ad, hipStream_t st) {
+  T* k = static_cast<T*>(kp);
+  T* g = static_cast<T*>(gi);
+  switch (n) {
+    case 1: return launch_adjoint<T, 1>(ptr, k, g, p, ad, st);
+    case 2: return launch_adjoint<T, 2>(ptr, k, g, p, ad, st);
+    case 3: return launch_adjoint<T, 3>(ptr, k, g, p, ad, st);
+    case 4: return launch_adjoint<T, 4>(ptr, k, g, p, ad, st);
+    case 5: return launch_adjoint<T, 5>(ptr, k, g, p, ad, st);
+    case 6: return launch_adjoint<T, 6>(ptr, k, g, p, ad, st);
+    case 7: return launch_adjoint<T, 7>(ptr, k, g, p, ad, st);
+    case 8: return launch_adjoint<T, 8>(ptr, k, g, p, ad, st);
+    case 9: return launch_adjoint<T, 9>(ptr, k, g, p, ad, st);
+    case 10: return launch_adjoint<T, 10>(ptr, k, g, p, ad, st);
+    default: return fail(QIDDM_ERR_UNSUPPORTED, "adjoint backward needs n_qubits <= 10 (got %d)", n);
+  }
+}
+
 // ---- n = 11..16: tiled kernel -----------------------------------------------------------------------
 int64_t tiled_blocks_x(int64_t batch, int64_t n_replicas) {
   if (n_replicas <= 0) return batch < 512 ? batch : 512;
@@ -483,6 +553,51 @@ int qiddm_forward_shifted(const qiddm_circuit_t* c, const void* inputs, int64_t 
   }
   return c->dtype == QIDDM_F32 ? dispatch_n<float, true>(c->n_qubits, ptr, p, n_replicas, st)
                                : dispatch_n<double, true>(c->n_qubits, ptr, p, n_replicas, st);
+}
+
+int64_t qiddm_adjoint_partials(const qiddm_circuit_t* c, int64_t batch) {
+  if (check_circuit(c) != QIDDM_OK || batch < 0) return -1;
+  if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED) return -1;
+  return adjoint_blocks_n(c->n_qubits, batch);
+}
+
+int qiddm_backward_adjoint(const qiddm_circuit_t* c, const void* inputs, int64_t batch, int64_t in_ld,
+                           const void* gate_table, const void* grad_out, int64_t g_ld, void* k_partials,
+                           void* grad_inputs, int64_t gin_ld, void* stream) {
+  int rc = check_circuit(c);
+  if (rc != QIDDM_OK) return rc;
+  if (c->n_rounds != 1)
+    return fail(QIDDM_ERR_UNSUPPORTED, "the adjoint pass differentiates one QNode round (n_rounds=%d)",
+                c->n_rounds);
+  if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED)
+    return fail(QIDDM_ERR_UNSUPPORTED, "adjoint backward needs n_qubits <= %d (got %d); use the "
+                "parameter-shift sweep", QIDDM_MAX_QUBITS_FUSED, c->n_qubits);
+  if (batch < 0) return fail(QIDDM_ERR_INVALID, "batch < 0");
+  if (!gate_table || !grad_out || !k_partials) return fail(QIDDM_ERR_INVALID, "gate_table/grad_out/k_partials is NULL");
+  if (c->encoding != QIDDM_ENC_NONE) {
+    if (!inputs) return fail(QIDDM_ERR_INVALID, "inputs is NULL but the encoding reads them");
+    if (in_ld < c->n_features)
+      return fail(QIDDM_ERR_INVALID, "in_ld=%lld < n_features=%d", (long long)in_ld, c->n_features);
+  }
+  if (g_ld < out_cols(c)) return fail(QIDDM_ERR_INVALID, "g_ld smaller than the output width");
+  const int64_t gin_cols = c->encoding == QIDDM_ENC_AMPLITUDE ? c->n_features : c->n_qubits;
+  if (grad_inputs && gin_ld < gin_cols) return fail(QIDDM_ERR_INVALID, "gin_ld=%lld < %lld", (long long)gin_ld, (long long)gin_cols);
+  qiddm::KScalars p = make_params(c);
+  Ptrs ptr;
+  ptr.inputs = inputs;
+  ptr.table = gate_table;
+  ptr.gout = grad_out;
+  p.in_ld = in_ld;
+  p.g_ld = g_ld;
+  p.batch = batch;
+  qiddm::AdjointScalars ad;
+  ad.gin_ld = gin_ld;
+  ad.want_inputs = (grad_inputs != nullptr && c->encoding != QIDDM_ENC_NONE) ? 1 : 0;
+  ad.pad_ = 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // batch == 0 still has to zero the (single) partial slab: launch with no samples
+  return c->dtype == QIDDM_F32 ? dispatch_adjoint<float>(c->n_qubits, ptr, k_partials, grad_inputs, p, ad, st)
+                               : dispatch_adjoint<double>(c->n_qubits, ptr, k_partials, grad_inputs, p, ad, st);
 }
 
 int qiddm_dense_forward(const qiddm_circuit_t* c, const double* x, int64_t batch, int64_t x_ld,

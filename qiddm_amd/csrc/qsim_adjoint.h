@@ -1,0 +1,404 @@
+// qsim_adjoint.h -- reverse-mode (adjoint) differentiation of the fused circuits, n <= 10.
+//
+// What PennyLane's diff_method="backprop" (reference nn/qdense.py:37, 246-alt, 419; nn/qconv.py:46)
+// obtains by keeping every intermediate state on the autograd tape, done the statevector way:
+//   forward once -> psi_final;   lambda = diag(g_eff) psi_final   (g_eff = upstream gradient folded on
+//   the measurement: d(sum_k g_k p_k) or d(sum_w g_w <Z_w>));  then walk the circuit backwards,
+//   un-applying every gate to BOTH vectors.  For a gate U(theta) on one wire
+//        dL/dtheta = 2 Re sum_{a,b} (dU/dtheta)_{ab} K_{ab},   K_{ab} = sum_pairs conj(lambda_a) psi_b
+//   with psi taken before and lambda after the gate.  The kernel accumulates the four complex K_{ab} of
+//   every Rot gate over all samples (they share the weights); the host contracts them with the analytic
+//   dRot/d(phi, theta, omega) in float64.  Per-sample input gradients (RZ / RY data encoding, amplitude
+//   embedding) are finished in the kernel.  Cost ~5 forward passes, independent of the number of
+//   parameters (a parameter-shift sweep costs 2 per parameter).
+#pragma once
+#include "qsim_fused.h"
+
+namespace qiddm {
+
+template <typename T>
+__device__ __forceinline__ V2<T> neg_i(V2<T> a) {
+  return V2<T>{a.y, -a.x};
+}
+// acc + conj(lam) * psi
+template <typename T>
+__device__ __forceinline__ V2<T> cjfma(V2<T> lam, V2<T> psi, V2<T> acc) {
+  return cfma<T>(lam, psi, neg_i<T>(psi), acc);
+}
+
+// Sum 8 per-lane values over the whole wave; value idx ends up (fully reduced) in the lane whose logical
+// number is < 8 with idx = 4*b0 + 2*b1 + b2 and is added to acc[idx] (LDS, private to the wave).
+// Halving exchange for the first three steps: 7 + 3 exchanged values instead of 48.
+template <typename T>
+__device__ __forceinline__ void wave_reduce8_into(const T (&v)[8], int lane, int llane, T* acc) {
+  const bool b0 = llane & 1, b1 = llane & 2, b2 = llane & 4;
+  T w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const T keep = b0 ? v[4 + i] : v[i];
+    const T send = b0 ? v[i] : v[4 + i];
+    w[i] = keep + xlane<1>(send, lane);
+  }
+  T u[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const T keep = b1 ? w[2 + i] : w[i];
+    const T send = b1 ? w[i] : w[2 + i];
+    u[i] = keep + xlane<2>(send, lane);
+  }
+  T t = (b2 ? u[1] : u[0]) + xlane<4>(b2 ? u[0] : u[1], lane);
+  t += xlane<8>(t, lane);
+  t += xlane<16>(t, lane);
+  t += xlane<32>(t, lane);
+  if (llane < 8) acc[(b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0)] += t;
+}
+
+struct AdjointScalars {
+  int64_t gin_ld;   // row stride of grad_inputs
+  int32_t want_inputs;
+  int32_t pad_;
+};
+
+template <typename T, int N>
+struct AdjointEngine {
+  using E = Engine<T, N>;
+  using L = typename E::L;
+  using C = V2<T>;
+  static constexpr int LB = L::LB, R = L::R, LPS = L::LPS;
+
+  E fwd;    // gate table U
+  E dag;    // same engine reading the dagger table U^dagger
+  T* kacc;  // this wave's K accumulators [n_rot][8] in LDS
+
+  // K_{ab} += conj(lambda_a) psib_b for one in-register pair, then both vectors are un-applied
+  template <int J>
+  __device__ __forceinline__ void step_regs(C (&psi)[R], C (&lam)[R], const C* m, T (&k)[8]) const {
+    const C* lo = m;
+    const C* hi = m + 4;
+    C k00{0, 0}, k01{0, 0}, k10{0, 0}, k11{0, 0};
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if ((r & J) == 0) {
+        const C a0 = psi[r], a1 = psi[r | J];
+        const C b0 = cfma<T>(a1, lo[2], lo[3], cmul2<T>(a0, lo[0], lo[1]));
+        const C b1 = cfma<T>(a0, hi[2], hi[3], cmul2<T>(a1, hi[0], hi[1]));
+        const C l0 = lam[r], l1 = lam[r | J];
+        k00 = cjfma<T>(l0, b0, k00);
+        k01 = cjfma<T>(l0, b1, k01);
+        k10 = cjfma<T>(l1, b0, k10);
+        k11 = cjfma<T>(l1, b1, k11);
+        psi[r] = b0;
+        psi[r | J] = b1;
+        lam[r] = cfma<T>(l1, lo[2], lo[3], cmul2<T>(l0, lo[0], lo[1]));
+        lam[r | J] = cfma<T>(l0, hi[2], hi[3], cmul2<T>(l1, hi[0], hi[1]));
+      }
+    }
+    k[0] = k00.x; k[1] = k00.y; k[2] = k01.x; k[3] = k01.y;
+    k[4] = k10.x; k[5] = k10.y; k[6] = k11.x; k[7] = k11.y;
+  }
+  // lane-bit version: this lane holds component a = its bit; `h` = the matching half of U^dagger
+  template <int Q>
+  __device__ __forceinline__ void step_lane(C (&psi)[R], C (&lam)[R], const C* h, C& s_own, C& s_x) const {
+    s_own = C{0, 0};
+    s_x = C{0, 0};
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const C own = psi[r];
+      const C par = xlane2<(1 << Q), T>(own, fwd.lane);
+      const C b = cfma<T>(par, h[2], h[3], cmul2<T>(own, h[0], h[1]));  // psi before the gate, own component
+      const C l_own = lam[r];
+      const C l_par = xlane2<(1 << Q), T>(l_own, fwd.lane);
+      s_own = cjfma<T>(l_own, b, s_own);  // K_{aa}
+      s_x = cjfma<T>(l_par, b, s_x);      // K_{(1-a) a}
+      psi[r] = b;
+      lam[r] = cfma<T>(l_par, h[2], h[3], cmul2<T>(l_own, h[0], h[1]));
+    }
+  }
+
+  // un-apply the Rot gate on wire W of the layer starting at gate0 and bank its K
+  template <int W>
+  __device__ __forceinline__ void rot_steps_back(C (&psi)[R], C (&lam)[R], int gate0) const {
+    if constexpr (W < N) {
+      constexpr int Q = N - 1 - W;
+      C m[8];
+      dag.template load_gate<W>(gate0, m);
+      T k[8];
+      if constexpr (E::template kind_of<W>() == E::kReg) {
+        step_regs<(1 << (Q >= LB ? Q - LB : 0))>(psi, lam, m, k);
+      } else if constexpr (E::template kind_of<W>() == E::kSwap) {
+        fwd.template swap_reg0_with_lane_bit<Q>(psi);
+        fwd.template swap_reg0_with_lane_bit<Q>(lam);
+        step_regs<1>(psi, lam, m, k);
+        fwd.template swap_reg0_with_lane_bit<Q>(psi);
+        fwd.template swap_reg0_with_lane_bit<Q>(lam);
+      } else {
+        C s_own, s_x;
+        step_lane<Q>(psi, lam, m, s_own, s_x);
+        const bool hi = (fwd.llane >> Q) & 1;
+        const T z = 0;
+        k[0] = hi ? z : s_own.x; k[1] = hi ? z : s_own.y;   // K00
+        k[2] = hi ? s_x.x : z;   k[3] = hi ? s_x.y : z;     // K01 = conj(lam_0) psib_1: held by bit-1 lanes
+        k[4] = hi ? z : s_x.x;   k[5] = hi ? z : s_x.y;     // K10
+        k[6] = hi ? s_own.x : z; k[7] = hi ? s_own.y : z;   // K11
+      }
+      wave_reduce8_into<T>(k, fwd.lane, fwd.llane, kacc + (size_t)(gate0 + W) * 8);
+      rot_steps_back<W + 1>(psi, lam, gate0);
+    }
+  }
+
+  // inverse entangler ring on one vector
+  __device__ __forceinline__ void ring_back(C (&a)[R], int ri, bool use_cnot) const {
+    if constexpr (N > 1) {
+      if (!use_cnot) {
+        fwd.ring(a, ri, false);  // CZ ring is its own inverse
+      } else {
+        const uint32_t lane_term = fwd.s_cn_lane[ri * kWave + fwd.llane];
+#pragma unroll
+        for (int r = 0; r < R; ++r) fwd.s_slab[(r << LB) | fwd.sub] = a[r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < R; ++r) a[r] = fwd.s_slab[lane_term ^ fwd.s_cn_reg[ri * R + r]];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+  }
+
+  // per-sample RY(x_w) un-application + d/dx_w (accumulated per lane into gx[w])
+  template <int W>
+  __device__ __forceinline__ void ry_steps_back(C (&psi)[R], C (&lam)[R], const T (&cs)[N], const T (&sn)[N],
+                                                T (&gx)[N]) const {
+    if constexpr (W < N) {
+      constexpr int Q = N - 1 - W;
+      const T c = cs[W], s = sn[W], z = 0;
+      if constexpr (Q >= LB) {
+        // RY^dagger = [[c, s], [-s, c]]
+        const C m[8] = {C{c, z}, C{z, c}, C{s, z}, C{z, s}, C{c, z}, C{z, c}, C{-s, z}, C{z, -s}};
+        T k[8];
+        step_regs<(1 << (Q >= LB ? Q - LB : 0))>(psi, lam, m, k);
+        // 2 Re sum (dRY/dtheta)_{ab} K_{ab},  dRY/dtheta = 1/2 [[-s, -c], [c, -s]]
+        gx[W] += -s * (k[0] + k[6]) + c * (k[4] - k[2]);
+      } else {
+        const bool hi = (fwd.llane >> Q) & 1;
+        const T sp = hi ? -s : s;  // partner coefficient of RY^dagger for this lane's row
+        const C h[4] = {C{c, z}, C{z, c}, C{sp, z}, C{z, sp}};
+        C s_own, s_x;
+        step_lane<Q>(psi, lam, h, s_own, s_x);
+        gx[W] += -s * s_own.x + (hi ? -c : c) * s_x.x;
+      }
+      ry_steps_back<W + 1>(psi, lam, cs, sn, gx);
+    }
+  }
+
+  // ---- one sample (group): forward, then the reverse sweep ------------------------------------------
+  // g_row: upstream gradient row ((2^N) probabilities or N expectation values).
+  // gin_row: where this sample's input gradient goes (may be null).
+  template <typename Src>
+  __device__ __forceinline__ void run(const KScalars& p, const Src& amp_src, T (&xs)[N],
+                                      const T* __restrict__ g_row, T* __restrict__ gin_row, bool valid) const {
+    const bool use_cnot = p.imprimitive == 0;
+    const int lane = fwd.lane, llane = fwd.llane, sub = fwd.sub;
+    C psi[R], dx[R];
+    T cs[N], sn[N];
+    T amp_inv = 1;
+    // ---- forward (one round) ---------------------------------------------------------------------
+    if (p.encoding == 1) {
+      T n2 = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int k = (r << LB) | sub;
+        T v = (T)p.pad_with;
+        if (k < p.n_features) v = amp_src(k) + (T)p.enc_offset;
+        psi[r] = C{v, (T)0};
+        n2 += v * v;
+      }
+      n2 = group_sum<T, LB>(n2, lane);
+      amp_inv = (T)1 / qsqrt(n2);
+#pragma unroll
+      for (int r = 0; r < R; ++r) psi[r] = C{psi[r].x * amp_inv, (T)0};
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) psi[r] = C{(T)0, (T)0};
+      psi[0] = C{sub == 0 ? (T)1 : (T)0, (T)0};
+    }
+    if (p.encoding == 2 || p.encoding == 3) fwd.half_angle_sincos(xs, cs, sn);
+    if (p.encoding == 2) fwd.rz_diagonal(cs, sn, dx);
+    {
+      C gate_m[8];
+      fwd.template load_gate<0>(0, gate_m);
+      const int n_rot = p.n_blocks * p.sel_layers * N;
+      for (int blk = 0; blk < p.n_blocks; ++blk) {
+        if (p.encoding == 2) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) psi[r] = cmul2<T>(dx[r], psi[r], times_i<T>(psi[r]));
+        } else if (p.encoding == 3 && blk == 0) {
+          fwd.template ry_layer<0>(psi, cs, sn);
+        }
+        for (int s = 0; s < p.sel_layers; ++s) {
+          const int gate0 = (blk * p.sel_layers + s) * N;
+          fwd.rot_layer(psi, gate0, gate0 + N < n_rot ? gate0 + N : 0, gate_m);
+          if constexpr (N > 1) fwd.ring(psi, s % (N - 1), use_cnot);
+        }
+      }
+    }
+    // ---- lambda = diag(g_eff) psi_final ----------------------------------------------------------------
+    C lam[R];
+    if (p.measure == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const T g = valid ? g_row[(r << LB) | sub] : (T)0;
+        lam[r] = C{g * psi[r].x, g * psi[r].y};
+      }
+    } else {
+      T gw[N];
+#pragma unroll
+      for (int w = 0; w < N; ++w) gw[w] = valid ? g_row[w] : (T)0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int k = (r << LB) | sub;
+        T g = 0;
+#pragma unroll
+        for (int w = 0; w < N; ++w) g += ((k >> (N - 1 - w)) & 1) ? -gw[w] : gw[w];
+        lam[r] = C{g * psi[r].x, g * psi[r].y};
+      }
+    }
+    // ---- reverse sweep ----------------------------------------------------------------------------------------
+    T gx[N];
+#pragma unroll
+    for (int w = 0; w < N; ++w) gx[w] = 0;
+    for (int blk = p.n_blocks - 1; blk >= 0; --blk) {
+      for (int s = p.sel_layers - 1; s >= 0; --s) {
+        if constexpr (N > 1) {
+          ring_back(psi, s % (N - 1), use_cnot);
+          ring_back(lam, s % (N - 1), use_cnot);
+        }
+        rot_steps_back<0>(psi, lam, (blk * p.sel_layers + s) * N);
+      }
+      if (p.encoding == 2) {
+        // d/dx_w of RZ_w(x_w): sum_k z_w(k) Im(conj(lambda_k) psi_k), psi right after the encoding layer
+        T t[R], tsum = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          t[r] = lam[r].x * psi[r].y - lam[r].y * psi[r].x;
+          tsum += t[r];
+        }
+#pragma unroll
+        for (int w = 0; w < N; ++w) {
+          const int q = N - 1 - w;
+          if (q >= LB) {
+            T acc = 0;
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc += ((r >> (q >= LB ? q - LB : 0)) & 1) ? -t[r] : t[r];
+            gx[w] += acc;
+          } else {
+            gx[w] += ((llane >> q) & 1) ? -tsum : tsum;
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          psi[r] = cmul2<T>(dx[r], psi[r], neg_i<T>(psi[r]));  // conj(dx) * psi
+          lam[r] = cmul2<T>(dx[r], lam[r], neg_i<T>(lam[r]));
+        }
+      } else if (p.encoding == 3 && blk == 0) {
+        ry_steps_back<0>(psi, lam, cs, sn, gx);
+      }
+    }
+    // ---- input gradients -----------------------------------------------------------------------------------------
+    if (gin_row != nullptr) {
+      if (p.encoding == 2 || p.encoding == 3) {
+        T v = 0;
+#pragma unroll
+        for (int w = 0; w < N; ++w) {
+          const T tot = group_sum<T, LB>(gx[w], lane) * (T)p.enc_scale;
+          v = fma((T)(sub == w ? 1 : 0), tot, v);
+        }
+        if (valid && sub < N) gin_row[sub] = v;
+      } else if (p.encoding == 1) {
+        // psi0 = v / |v| (real): dL/dv_k = (gpsi_k - psi0_k <gpsi, psi0>) / |v|, gpsi = 2 Re lambda_0
+        T dotp = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) dotp += (T)2 * lam[r].x * psi[r].x;
+        dotp = group_sum<T, LB>(dotp, lane);
+        if (valid) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int k = (r << LB) | sub;
+            if (k < p.n_features) gin_row[k] = ((T)2 * lam[r].x - psi[r].x * dotp) * amp_inv;
+          }
+        }
+      }
+    }
+  }
+};
+
+// ---------------------------------------------------------------------------
+// kernel: grid-strided over samples; every block writes its K partial slab [n_rot][8]
+// ---------------------------------------------------------------------------
+template <typename T, int N>
+__global__ __launch_bounds__(4 * kWave) void adjoint_kernel(const T* __restrict__ inputs,
+                                                            const T* __restrict__ table,
+                                                            const T* __restrict__ gout,
+                                                            T* __restrict__ k_partials,
+                                                            T* __restrict__ grad_inputs, const KScalars p,
+                                                            const AdjointScalars ad) {
+  using E = Engine<T, N>;
+  using L = typename E::L;
+  using S = Smem<T, N>;
+  constexpr int LB = L::LB, SPW = L::SPW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int n_rot = p.n_blocks * p.sel_layers * N;
+  const int waves = blockDim.x >> 6;
+  AdjointEngine<T, N> adj;
+  adj.fwd.carve(smem_raw, n_rot);
+  // after the forward engine's region: dagger gate table, then the per-wave K accumulators
+  unsigned char* extra = smem_raw + S::bytes(n_rot, p.imprimitive == 0, waves);
+  T* dag_gates = reinterpret_cast<T*>(extra);
+  T* kall = dag_gates + (size_t)n_rot * kLdsGateReals;
+  adj.fwd.fill_gates_from_table(table, n_rot, -1, 0);
+  for (int g = threadIdx.x; g < n_rot; g += blockDim.x) {
+    const T* u = table + (size_t)g * kVariants * kGateReals;
+    // U^dagger: (u00*, u10*; u01*, u11*)
+    E::put_gate(dag_gates + (size_t)g * kLdsGateReals, u[0], -u[1], u[4], -u[5], u[2], -u[3], u[6], -u[7]);
+  }
+  for (int i = threadIdx.x; i < waves * n_rot * 8; i += blockDim.x) kall[i] = 0;
+  adj.fwd.fill_rings(p.imprimitive == 0);
+  __syncthreads();
+  adj.dag = adj.fwd;
+  adj.dag.s_gates = dag_gates;
+  const int wave = threadIdx.x >> 6;
+  adj.kacc = kall + (size_t)wave * n_rot * 8;
+  const int sub = adj.fwd.sub;
+  const int swave = adj.fwd.llane >> LB;
+
+  const int64_t groups = (p.batch + SPW - 1) / SPW;
+  for (int64_t grp = (int64_t)blockIdx.x * waves + wave; grp < groups; grp += (int64_t)gridDim.x * waves) {
+    const int64_t sample_raw = grp * SPW + swave;
+    const bool valid = sample_raw < p.batch;
+    const int64_t sample = valid ? sample_raw : p.batch - 1;
+    T xs[N];
+    if (p.encoding == 2 || p.encoding == 3) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) xs[j] = inputs[sample * p.in_ld + j] * (T)p.enc_scale;
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; ++j) xs[j] = (T)0;
+    }
+    // an out-of-range slot (sub-wave layouts only) repeats the last sample with a zero upstream
+    // gradient: it still takes part in the wave-wide exchanges but adds nothing to K
+    const T* g_row = gout + sample * p.g_ld;
+    T* gin_row = ad.want_inputs ? grad_inputs + sample * ad.gin_ld : nullptr;
+    adj.run(p, RowSrc<T>{inputs + sample * p.in_ld}, xs, g_row, gin_row, valid);
+  }
+  __syncthreads();
+  // block partial: sum the waves' accumulators in a fixed order (deterministic)
+  for (int i = threadIdx.x; i < n_rot * 8; i += blockDim.x) {
+    T tot = 0;
+    for (int w = 0; w < waves; ++w) tot += kall[(size_t)w * n_rot * 8 + i];
+    k_partials[(size_t)blockIdx.x * n_rot * 8 + i] = tot;
+  }
+}
+
+}  // namespace qiddm

@@ -210,7 +210,7 @@ class QNode:
         n = self.device.num_wires
         circ, x, angles, batched, as_list = _compile(tape, ret, n, self.device)
         self.circuit = circ
-        out = _c.execute(circ, x, angles, self.precision)
+        out = _c.execute(circ, x, angles, self.precision, self.diff_method or "backprop")
         out_dtype = _result_dtype(x, angles)
         out = out.to(out_dtype)
         if not batched:

@@ -1,0 +1,106 @@
+"""GPU parity of the adjoint (reverse-mode) backward against torch autograd through the CPU oracle --
+what the reference's diff_method="backprop" QNodes compute (nn/qdense.py:37, 419; nn/qconv.py:46)."""
+import pytest
+import torch
+
+from oracle import circuits as oc
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(n, enc, imp, meas, L, S, batch, seed, feat=None, pad=0.0, offset=0.0, scale=1.0):
+    from qiddm_amd.circuit import Circuit
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(1, L, S, n, 3, generator=g, dtype=torch.float64) * 0.8
+    f = feat if feat is not None else n
+    x = torch.rand(batch, f, generator=g, dtype=torch.float64) * 2 - 0.5
+    if enc == "amplitude":
+        x = x.abs() + 0.05
+    circ = Circuit(n_qubits=n, encoding=enc, imprimitive=imp, measure=meas, n_blocks=L, sel_layers=S,
+                   n_features=f if enc == "amplitude" else 0, pad_with=pad, enc_offset=offset, enc_scale=scale)
+    spec = oc.Spec(n=n, encoding=enc, imprimitive=imp, measure=meas, pad_with=pad, enc_offset=offset,
+                   enc_scale=scale)
+    cols = 2 ** n if meas == "probs" else n
+    gout = torch.randn(batch, cols, generator=g, dtype=torch.float64)
+    return circ, spec, x, w, gout
+
+
+def _oracle_grads(spec, x, w, gout):
+    w = w.clone().requires_grad_(True)
+    x = x.clone().requires_grad_(True)
+    loss = (oc.run_circuit(spec, x, w) * gout).sum()
+    return torch.autograd.grad(loss, [w, x])
+
+
+CASES = [
+    (1, "rz", "CZ", "expz", 2, 2), (2, "rz", "CNOT", "probs", 2, 3), (3, "rz", "CZ", "expz", 2, 2),
+    (4, "rz", "CZ", "probs", 3, 2), (5, "ry", "CNOT", "probs", 1, 3), (6, "rz", "CNOT", "expz", 2, 3),
+    (7, "ry", "CNOT", "probs", 1, 3), (8, "rz", "CZ", "expz", 2, 2), (8, "rz", "CNOT", "probs", 2, 9),
+    (9, "rz", "CZ", "probs", 1, 2), (10, "rz", "CZ", "expz", 2, 2), (10, "rz", "CNOT", "probs", 1, 3),
+    (4, "amplitude", "CNOT", "probs", 1, 3), (7, "amplitude", "CNOT", "probs", 1, 2),
+    (10, "amplitude", "CNOT", "probs", 1, 2), (3, "amplitude", "CZ", "expz", 1, 2),
+]
+
+
+@pytest.mark.parametrize("precision,tol", [("f64", dict(atol=1e-9, rtol=1e-9)), ("f32", dict(atol=3e-4, rtol=3e-3))])
+@pytest.mark.parametrize("n,enc,imp,meas,L,S", CASES)
+def test_adjoint_matches_autograd(n, enc, imp, meas, L, S, precision, tol):
+    from qiddm_amd.circuit import run_adjoint
+    feat = {4: 9, 7: 100, 10: 784, 3: 8}.get(n) if enc == "amplitude" else None
+    circ, spec, x, w, gout = _case(n, enc, imp, meas, L, S, batch=21, seed=n * 13 + L, feat=feat, pad=0.3,
+                                   offset=0.1 if enc == "amplitude" else 0.0, scale=1.3 if enc != "amplitude" else 1.0)
+    ga, gi = run_adjoint(circ, x.cuda(), w.cuda(), gout.cuda(), precision)
+    torch.cuda.synchronize()
+    ra, ri = _oracle_grads(spec, x, w, gout)
+    assert torch.allclose(ga.cpu(), ra, **tol), (ga.cpu() - ra).abs().max()
+    cols = gi.shape[1]
+    assert torch.allclose(gi.cpu(), ri[:, :cols], **tol), (gi.cpu() - ri[:, :cols]).abs().max()
+
+
+def test_adjoint_equals_parameter_shift():
+    from qiddm_amd.circuit import run_adjoint, run_shift_sweep
+    circ, spec, x, w, gout = _case(8, "rz", "CZ", "expz", 3, 2, batch=300, seed=77)
+    a1, i1 = run_adjoint(circ, x.cuda(), w.cuda(), gout.cuda(), "f64")
+    a2, i2 = run_shift_sweep(circ, x.cuda(), w.cuda(), gout.cuda(), "f64")
+    assert torch.allclose(a1, a2, atol=1e-9) and torch.allclose(i1, i2, atol=1e-10)
+
+
+def test_qconv_stack_trains_through_the_adjoint():
+    """Two stacked QConv2d layers: the inner layer's features need d/d(amplitude-embedded input)."""
+    from qiddm_amd import nn, set_default_precision
+    torch.manual_seed(5)
+    c1 = nn.QConv2d(1, 4, 3, 1, 2).cuda()
+    c2 = nn.QConv2d(4, 2, 3, 1, 2).cuda()
+    x = torch.rand(2, 1, 5, 5, dtype=torch.float64)
+    set_default_precision("f64")
+    try:
+        y = c2(c1(x.cuda()))
+        y.square().sum().backward()
+    finally:
+        set_default_precision("f32")
+    w1 = c1.weights.detach().cpu().clone().requires_grad_(True)
+    w2 = c2.weights.detach().cpu().clone().requires_grad_(True)
+    ref = oc.qconv2d_forward(oc.qconv2d_forward(x, w1, 4), w2, 2)
+    ref.square().sum().backward()
+    assert torch.allclose(y.detach().cpu(), ref.detach(), atol=1e-10)
+    assert torch.allclose(c2.weights.grad.cpu(), w2.grad, atol=1e-8), (c2.weights.grad.cpu() - w2.grad).abs().max()
+    assert torch.allclose(c1.weights.grad.cpu(), w1.grad, atol=1e-8), (c1.weights.grad.cpu() - w1.grad).abs().max()
+
+
+def test_differn_backprop_training_step():
+    """differN (diff_method='backprop') end to end: chained rounds, grads == oracle autograd."""
+    from qiddm_amd import nn, set_default_precision
+    torch.manual_seed(6)
+    m = nn.differN_noise(8, 3, 2).cuda()
+    red = torch.randn(9, 6) * 1.5
+    set_default_precision("f64")
+    try:
+        out = m.forward_from_reduced(red.cuda())
+        out.sum().backward()
+    finally:
+        set_default_precision("f32")
+    w = m.weights.detach().cpu().clone().requires_grad_(True)
+    ref = oc.differn_from_reduced(red, w, (8, 8))
+    ref.sum().backward()
+    assert torch.allclose(out.detach().cpu(), ref.detach(), atol=1e-9)
+    assert torch.allclose(m.weights.grad.cpu().double(), w.grad.double(), atol=1e-7)
