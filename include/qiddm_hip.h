@@ -34,6 +34,7 @@
  *     for block in 0..n_blocks-1:                data re-uploading, nn/qdense.py:424-428
  *       QIDDM_ENC_RZ : RZ(enc_scale * x_j) on every wire j
  *       QIDDM_ENC_RY : RY(enc_scale * x_j) on every wire j, block 0 only (qml.AngleEmbedding)
+ *       QIDDM_ENC_RY_BLOCKS : the same RY layer in front of every block
  *       StronglyEntanglingLayers(angles[round][block] : (sel_layers, n, 3), imprimitive)
  *     out <- probs (B, 2^n)  |  <Z_i> (B, n)
  *     x   <- out[:, 0:n]     (input of the next round)
@@ -63,7 +64,8 @@ typedef enum qiddm_encoding {
   QIDDM_ENC_NONE = 0,
   QIDDM_ENC_AMPLITUDE = 1, /* qml.AmplitudeEmbedding  (nn/qdense.py:41-43, nn/qconv.py:52-54) */
   QIDDM_ENC_RZ = 2,        /* qml.RZ(inputs[:, j], wires=j) (nn/qdense.py:253, 427, 1408)     */
-  QIDDM_ENC_RY = 3         /* qml.AngleEmbedding(rotation="Y") (nn/qdense.py:166-168)        */
+  QIDDM_ENC_RY = 3,        /* qml.AngleEmbedding(rotation="Y"): once, before block 0 (nn/qdense.py:166-168) */
+  QIDDM_ENC_RY_BLOCKS = 4  /* qml.RY(inputs[j], wires=j) re-uploaded in every block (nn/qdense.py:600-602) */
 } qiddm_encoding;
 
 typedef enum qiddm_imprimitive {

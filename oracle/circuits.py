@@ -58,7 +58,7 @@ def run_round(spec: Spec, inputs, weights):
     for blk in range(w.shape[0]):
         if spec.encoding == "rz":
             st = sv.angle_embedding_rz(st, x, n, scale=spec.enc_scale)
-        elif spec.encoding == "ry" and (blk == 0 or not spec.ry_once):
+        elif spec.encoding in ("ry", "ry_blocks") and (blk == 0 or spec.encoding == "ry_blocks" or not spec.ry_once):
             st = sv.angle_embedding_ry(st, x * spec.enc_scale, n)
         st = sv.strongly_entangling_layers(st, w[blk], n, spec.imprimitive)
     if spec.measure == "probs":
@@ -88,6 +88,8 @@ def gate_count(spec: Spec, n_rounds: int, n_blocks: int, sel_layers: int) -> int
     g = n_rounds * n_blocks * per_block
     if spec.encoding == "ry":
         g += n_rounds * n
+    if spec.encoding == "ry_blocks":
+        g += n_rounds * n_blocks * n
     if spec.encoding == "amplitude":
         g += n_rounds
     return g

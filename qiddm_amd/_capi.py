@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libqiddm_hip.so")
 
 QIDDM_OK = 0
-ENC_NONE, ENC_AMPLITUDE, ENC_RZ, ENC_RY = 0, 1, 2, 3
+ENC_NONE, ENC_AMPLITUDE, ENC_RZ, ENC_RY, ENC_RY_BLOCKS = 0, 1, 2, 3, 4
 IMP_CNOT, IMP_CZ = 0, 1
 MEAS_PROBS, MEAS_EXPZ = 0, 1
 F32, F64 = 0, 1

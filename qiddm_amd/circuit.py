@@ -17,7 +17,8 @@ import torch
 
 from . import _capi
 
-_ENC = {"none": _capi.ENC_NONE, "amplitude": _capi.ENC_AMPLITUDE, "rz": _capi.ENC_RZ, "ry": _capi.ENC_RY}
+_ENC = {"none": _capi.ENC_NONE, "amplitude": _capi.ENC_AMPLITUDE, "rz": _capi.ENC_RZ, "ry": _capi.ENC_RY,
+        "ry_blocks": _capi.ENC_RY_BLOCKS}
 _IMP = {"CNOT": _capi.IMP_CNOT, "CZ": _capi.IMP_CZ}
 _MEAS = {"probs": _capi.MEAS_PROBS, "expz": _capi.MEAS_EXPZ}
 _DT = {"f32": (_capi.F32, torch.float32), "f64": (_capi.F64, torch.float64)}
@@ -42,7 +43,7 @@ class Circuit:
     """Host mirror of ``qiddm_circuit_t`` (see include/qiddm_hip.h for the family)."""
 
     n_qubits: int
-    encoding: str = "rz"       # "none" | "amplitude" | "rz" | "ry"
+    encoding: str = "rz"       # "none" | "amplitude" | "rz" | "ry" (once) | "ry_blocks" (every block)
     imprimitive: str = "CZ"    # "CNOT" | "CZ"
     measure: str = "expz"      # "probs" | "expz"
     n_rounds: int = 1
@@ -72,7 +73,7 @@ class Circuit:
 
     @property
     def features(self) -> int:
-        if self.encoding in ("rz", "ry"):
+        if self.encoding in ("rz", "ry", "ry_blocks"):
             return self.n_features or self.n_qubits
         return self.n_features
 
@@ -93,6 +94,8 @@ class Circuit:
         g = self.n_rounds * self.n_blocks * per_block
         if self.encoding == "ry":
             g += self.n_rounds * n
+        if self.encoding == "ry_blocks":
+            g += self.n_rounds * self.n_blocks * n
         if self.encoding == "amplitude":
             g += self.n_rounds
         return g
@@ -272,7 +275,7 @@ def run_shift_sweep(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch
     cs = circ.c_struct(precision)
     table = prepare_gates(circ, angles, precision)
     g = grad_out.to(device=device, dtype=dtype).contiguous()
-    want_inputs = with_inputs and circ.encoding in ("rz", "ry")
+    want_inputs = with_inputs and circ.encoding in ("rz", "ry", "ry_blocks")
     total = lib.qiddm_num_shift_replicas(ctypes.byref(cs), 1 if want_inputs else 0)
     n_rot = lib.qiddm_num_rot_gates(ctypes.byref(cs))
     chunk = max(2, min(65534, (max_dots_elems // max(batch, 1)) // 2 * 2, total))

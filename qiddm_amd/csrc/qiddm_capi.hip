@@ -31,7 +31,7 @@ int check_circuit(const qiddm_circuit_t* c) {
   if (c->n_qubits < 1) return fail(QIDDM_ERR_INVALID, "n_qubits=%d must be >= 1", c->n_qubits);
   if (c->n_qubits > QIDDM_MAX_QUBITS)
     return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d exceeds the limit %d", c->n_qubits, QIDDM_MAX_QUBITS);
-  if (c->encoding < QIDDM_ENC_NONE || c->encoding > QIDDM_ENC_RY)
+  if (c->encoding < QIDDM_ENC_NONE || c->encoding > QIDDM_ENC_RY_BLOCKS)
     return fail(QIDDM_ERR_INVALID, "unknown encoding %d", c->encoding);
   if (c->imprimitive != QIDDM_IMP_CNOT && c->imprimitive != QIDDM_IMP_CZ)
     return fail(QIDDM_ERR_INVALID, "unknown imprimitive %d", c->imprimitive);
@@ -51,12 +51,10 @@ int check_circuit(const qiddm_circuit_t* c) {
                   (long long)d, c->n_features);
     if (c->n_rounds != 1)
       return fail(QIDDM_ERR_UNSUPPORTED, "amplitude encoding supports n_rounds == 1 only");
-  } else if (c->encoding == QIDDM_ENC_RZ || c->encoding == QIDDM_ENC_RY) {
+  } else if (c->encoding >= QIDDM_ENC_RZ) {
     if (c->n_features < c->n_qubits)
       return fail(QIDDM_ERR_INVALID, "angle encoding needs n_features >= n_qubits (%d < %d)",
                   c->n_features, c->n_qubits);
-    if (c->encoding == QIDDM_ENC_RY && c->n_blocks != 1)
-      return fail(QIDDM_ERR_UNSUPPORTED, "RY (AngleEmbedding) encoding supports n_blocks == 1 only");
   }
   if ((int64_t)c->n_rounds * c->n_blocks * c->sel_layers * c->n_qubits > (1 << 24))
     return fail(QIDDM_ERR_UNSUPPORTED, "too many Rot gates");
@@ -431,6 +429,7 @@ int64_t qiddm_gate_count(const qiddm_circuit_t* c) {
   if (c->encoding == QIDDM_ENC_RZ) per_block += n;
   int64_t g = (int64_t)c->n_rounds * c->n_blocks * per_block;
   if (c->encoding == QIDDM_ENC_RY) g += (int64_t)c->n_rounds * n;
+  if (c->encoding == QIDDM_ENC_RY_BLOCKS) g += (int64_t)c->n_rounds * c->n_blocks * n;
   if (c->encoding == QIDDM_ENC_AMPLITUDE) g += c->n_rounds;
   return g;
 }
@@ -444,7 +443,7 @@ int64_t qiddm_num_shift_replicas(const qiddm_circuit_t* c, int with_inputs) {
   const int64_t g = qiddm_num_rot_gates(c);
   if (g < 0) return g;
   int64_t r = 6 * g;
-  if (with_inputs && (c->encoding == QIDDM_ENC_RZ || c->encoding == QIDDM_ENC_RY))
+  if (with_inputs && c->encoding >= QIDDM_ENC_RZ)
     r += 2 * (int64_t)c->n_blocks * c->n_qubits;
   return r;
 }

@@ -224,7 +224,7 @@ struct AdjointEngine {
       for (int r = 0; r < R; ++r) psi[r] = C{(T)0, (T)0};
       psi[0] = C{sub == 0 ? (T)1 : (T)0, (T)0};
     }
-    if (p.encoding == 2 || p.encoding == 3) fwd.half_angle_sincos(xs, cs, sn);
+    if (p.encoding >= 2) fwd.half_angle_sincos(xs, cs, sn);
     if (p.encoding == 2) fwd.rz_diagonal(cs, sn, dx);
     {
       C gate_m[8];
@@ -234,7 +234,7 @@ struct AdjointEngine {
         if (p.encoding == 2) {
 #pragma unroll
           for (int r = 0; r < R; ++r) psi[r] = cmul2<T>(dx[r], psi[r], times_i<T>(psi[r]));
-        } else if (p.encoding == 3 && blk == 0) {
+        } else if ((p.encoding == 3 && blk == 0) || p.encoding == 4) {
           fwd.template ry_layer<0>(psi, cs, sn);
         }
         for (int s = 0; s < p.sel_layers; ++s) {
@@ -302,13 +302,13 @@ struct AdjointEngine {
           psi[r] = cmul2<T>(dx[r], psi[r], neg_i<T>(psi[r]));  // conj(dx) * psi
           lam[r] = cmul2<T>(dx[r], lam[r], neg_i<T>(lam[r]));
         }
-      } else if (p.encoding == 3 && blk == 0) {
+      } else if ((p.encoding == 3 && blk == 0) || p.encoding == 4) {
         ry_steps_back<0>(psi, lam, cs, sn, gx);
       }
     }
     // ---- input gradients -----------------------------------------------------------------------------------------
     if (gin_row != nullptr) {
-      if (p.encoding == 2 || p.encoding == 3) {
+      if (p.encoding >= 2) {
         T v = 0;
 #pragma unroll
         for (int w = 0; w < N; ++w) {
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(4 * kWave) void adjoint_kernel(const T* __restrict_
     const bool valid = sample_raw < p.batch;
     const int64_t sample = valid ? sample_raw : p.batch - 1;
     T xs[N];
-    if (p.encoding == 2 || p.encoding == 3) {
+    if (p.encoding >= 2) {
 #pragma unroll
       for (int j = 0; j < N; ++j) xs[j] = inputs[sample * p.in_ld + j] * (T)p.enc_scale;
     } else {

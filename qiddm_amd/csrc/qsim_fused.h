@@ -591,7 +591,7 @@ struct Engine {
         for (int r = 0; r < R; ++r) a[r] = C{(T)0, (T)0};
         a[0] = C{sub == 0 ? (T)1 : (T)0, (T)0};
       }
-      if (p.encoding == 2 || p.encoding == 3) half_angle_sincos(xs, cs, sn);
+      if (p.encoding >= 2) half_angle_sincos(xs, cs, sn);
       if (p.encoding == 2) rz_diagonal(cs, sn, dx);
 
       // ---- blocks -----------------------------------------------------------------------
@@ -609,19 +609,24 @@ struct Engine {
               a[r] = C{a[r].x * h - a[r].y * si, a[r].x * si + a[r].y * h};
             }
           }
-        } else if (p.encoding == 3 && blk == 0) {
-          if (sh.blk == 0) {  // parameter shift of one RY input angle: rotate (c, s) by +-pi/4
+        } else if ((p.encoding == 3 && blk == 0) || p.encoding == 4) {
+          T cb[N], sb[N];
+#pragma unroll
+          for (int j = 0; j < N; ++j) {
+            cb[j] = cs[j];
+            sb[j] = sn[j];
+          }
+          if (sh.blk == blk) {  // parameter shift of one RY input angle: rotate (c, s) by +-pi/4
             const T h = (T)0.70710678118654752440;
 #pragma unroll
             for (int j = 0; j < N; ++j) {
               if (j == sh.wire) {
-                const T c = cs[j], s = sn[j];
-                cs[j] = h * (c - sh.sign * s);
-                sn[j] = h * (s + sh.sign * c);
+                cb[j] = h * (cs[j] - sh.sign * sn[j]);
+                sb[j] = h * (sn[j] + sh.sign * cs[j]);
               }
             }
           }
-          ry_layer<0>(a, cs, sn);
+          ry_layer<0>(a, cb, sb);
         }
         for (int s = 0; s < p.sel_layers; ++s) {
           const int gate0 = ((round * p.n_blocks + blk) * p.sel_layers + s) * N;
@@ -730,7 +735,7 @@ __global__ __launch_bounds__(4 * kWave) void circuit_kernel(const T* __restrict_
     const int64_t sample = valid ? sample_raw : p.batch - 1;
 
     T xs[N];
-    if (p.encoding == 2 || p.encoding == 3) {
+    if (p.encoding >= 2) {
 #pragma unroll
       for (int j = 0; j < N; ++j) xs[j] = inputs[sample * p.in_ld + j] * (T)p.enc_scale;
     } else {

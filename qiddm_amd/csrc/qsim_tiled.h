@@ -107,7 +107,7 @@ struct ProgramBuilder {
       for (int w = 0; w < n; ++w) {
         const int tb = tile_bit(cur, n - 1 - w);
         if (tb >= 0 && !((done >> w) & 1u)) {
-          emit(make_op(type, (uint32_t)tb, (uint32_t)(type == kOpRot ? gate0 + w : w)));
+          emit(make_op(type, (uint32_t)tb, (uint32_t)(type == kOpRot ? gate0 + w : (w | (gate0 << 8)))));
           done |= 1u << w;
         }
       }
@@ -123,7 +123,7 @@ struct ProgramBuilder {
     open(0, 1);
     for (int blk = 0; blk < n_blocks; ++blk) {
       if (encoding == 2) emit(make_op(kOpDiagX, 0, (uint32_t)blk));
-      if (encoding == 3 && blk == 0) layer(kOpRyX, 0);
+      if ((encoding == 3 && blk == 0) || encoding == 4) layer(kOpRyX, blk);  // gate0 slot carries the block
       for (int s = 0; s < sel_layers; ++s) {
         layer(kOpRot, (blk * sel_layers + s) * n);
         const int range = (s % (n - 1)) + 1;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(kTiledWaves* kWave) void tiled_circuit_kernel(
   for (int64_t sample = blockIdx.x; sample < p.batch; sample += gridDim.x) {
     const T* __restrict__ in_row = inputs + sample * p.in_ld;
     // ---- round-0 inputs ---------------------------------------------------------------------------
-    if (tid < n) s_xs[tid] = (p.encoding == 2 || p.encoding == 3) ? (double)in_row[tid] * p.enc_scale : 0.0;
+    if (tid < n) s_xs[tid] = p.encoding >= 2 ? (double)in_row[tid] * p.enc_scale : 0.0;
     T amp_inv = 1;
     if (p.encoding == 1) {  // amplitude embedding: norm over features + constant padding
       double part = 0.0;
@@ -251,15 +251,9 @@ __global__ __launch_bounds__(kTiledWaves* kWave) void tiled_circuit_kernel(
     T dot_acc = 0;  // SHIFT + probs: sum_k g_k p_k of this lane
     for (int round = 0; round < p.n_rounds; ++round) {
       __syncthreads();  // s_xs of this round is complete
-      if (tid < n && (p.encoding == 2 || p.encoding == 3)) {
+      if (tid < n && p.encoding >= 2) {
         double s, c;
         sincos(0.5 * s_xs[tid], &s, &c);
-        if (p.encoding == 3 && sh_blk == 0 && tid == sh_wire) {  // shifted RY input angle
-          const double h = 0.70710678118654752440, sg = (double)sh_sign;
-          const double c2 = h * (c - sg * s), s2 = h * (s + sg * c);
-          c = c2;
-          s = s2;
-        }
         s_cs[tid] = c;
         s_sn[tid] = s;
       }
@@ -341,7 +335,17 @@ __global__ __launch_bounds__(kTiledWaves* kWave) void tiled_circuit_kernel(
                   for (int i = 0; i < 8; ++i) m[i] = gp[i];
                 }
               } else {
-                const T c = (T)s_cs[arg], s = (T)s_sn[arg], z = 0;
+                const int ry_wire = (int)(arg & 255u), ry_blk = (int)(arg >> 8);
+                T c = (T)s_cs[ry_wire], s = (T)s_sn[ry_wire];
+                const T z = 0;
+                if constexpr (SHIFT) {
+                  if (ry_blk == sh_blk && ry_wire == sh_wire) {  // shifted RY input angle: +-pi/4 on the half angle
+                    const T h = (T)0.70710678118654752440;
+                    const T c2 = h * (c - sh_sign * s), s2 = h * (s + sh_sign * c);
+                    c = c2;
+                    s = s2;
+                  }
+                }
                 if (tb < 4) {
                   const T sp = ((llane >> tb) & 1) ? s : -s;
                   m[0] = C{c, z}; m[1] = C{z, c}; m[2] = C{sp, z}; m[3] = C{z, sp};

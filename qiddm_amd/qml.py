@@ -286,27 +286,28 @@ def _compile(tape, ret, n, dev):
     blocks, rz_cols, imp = [], None, None
     while i < len(tape):
         op = tape[i]
-        if op.name == "RZ":
+        if op.name in ("RZ", "RY"):
+            kind, this_enc = op.name, ("rz" if op.name == "RZ" else "ry_blocks")
             cols = []
             for j in range(n):
-                if i >= len(tape) or tape[i].name != "RZ" or tape[i].wires != (j,):
-                    raise NotImplementedError("RZ encoders must cover wires 0..n-1 in order")
+                if i >= len(tape) or tape[i].name != kind or tape[i].wires != (j,):
+                    raise NotImplementedError(f"{kind} encoders must cover wires 0..n-1 in order")
                 cols.append(tape[i].params[0])
                 i += 1
-            if enc not in ("none", "rz") or (enc == "none" and blocks):
+            if enc not in ("none", this_enc) or (enc == "none" and blocks):
                 raise NotImplementedError("mixed encodings in one circuit")
             if rz_cols is None:
                 rz_cols = cols
             elif not all(_same_view(a, b) for a, b in zip(rz_cols, cols)):
                 raise NotImplementedError("every block must re-upload the same inputs")
-            enc = "rz"
+            enc = this_enc
             if i >= len(tape) or tape[i].name != "StronglyEntanglingLayers":
-                raise NotImplementedError("an RZ encoder layer must be followed by StronglyEntanglingLayers")
+                raise NotImplementedError("an encoder layer must be followed by StronglyEntanglingLayers")
             continue
         if op.name == "StronglyEntanglingLayers":
             if op.wires != all_w:
                 raise NotImplementedError("StronglyEntanglingLayers must act on all wires")
-            if enc == "rz" and len(blocks) >= 1 and rz_cols is None:
+            if enc in ("rz", "ry_blocks") and len(blocks) >= 1 and rz_cols is None:
                 raise NotImplementedError("blocks without encoder after blocks with encoder")
             this_imp = op.hyper["imprimitive"]
             if imp is not None and this_imp != imp:
@@ -324,9 +325,9 @@ def _compile(tape, ret, n, dev):
         raise NotImplementedError(f"operation {op.name} is outside the supported circuit family")
     if not blocks:
         raise NotImplementedError("circuit has no StronglyEntanglingLayers block")
-    if enc == "rz" and len(blocks) > 1:
+    if enc in ("rz", "ry_blocks") and len(blocks) > 1:
         # the pattern requires an encoder in front of every block
-        n_rz = sum(1 for t in tape if t.name == "RZ")
+        n_rz = sum(1 for t in tape if t.name == ("RZ" if enc == "rz" else "RY"))
         if n_rz != n * len(blocks):
             raise NotImplementedError("every StronglyEntanglingLayers block needs its RZ encoder layer")
     s_layers = blocks[0].shape[0]
@@ -335,7 +336,7 @@ def _compile(tape, ret, n, dev):
     angles = torch.stack([b for b in blocks], dim=0).unsqueeze(0)  # (1, L, S, n, 3)
 
     batched = True
-    if enc == "rz":
+    if enc in ("rz", "ry_blocks"):
         cols = [c if torch.is_tensor(c) else torch.as_tensor(c) for c in rz_cols]
         batched = cols[0].dim() >= 1
         x = torch.stack([c.reshape(-1) for c in cols], dim=-1)  # (B, n)

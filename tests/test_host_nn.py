@@ -163,3 +163,44 @@ def test_quantum_forward_on_cpu_fails_loudly():
         m(torch.rand(2, 1, 8, 8, dtype=torch.double))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         nn.QConv2d(1, 8, 3, 1, 2)(torch.rand(1, 1, 5, 5))
+
+
+def test_all_27_dense_classes_exist_with_reference_names():
+    """Every class of reference nn/qdense.py (SURVEY.md section 8a list) + save_name() strings."""
+    expect = {
+        "QDenseUndirected_old": ((3, 8), "QDenseUndirected_old3_w8_h8"),
+        "QDenseUndirected_old_noise": ((3, 8), "QDenseUndirected_old_noise3_w8_h8_noise0"),
+        "QNN_A": ((3, 8), "QNN_A3_w8_h8_noise0"),
+        "QNN_noise": ((64, 4, 2), "QNN_linear_features=4_qdepth=2_add_noise=0"),
+        "QNN": ((64, 4, 2), "QNN_linear_features=4_qdepth=2"),
+        "differN_noise": ((8, 2, 2), "differN_old_pca=2_N=2_w8_h8_noise0"),
+        "differN_noise_befor": ((8, 2, 2), "differN_noise=2_N=2_w8_h8"),
+        "QIDDM_PL_noise1": ((64, 4, 2, 1), "QIDDM_PL_noise=4_L=2_N=1"),
+        "differN_old_pca": ((8, 2, 2), "differN_old_pca=2_N=2_w8_h8"),
+        "differN_new_pca": ((8, 2, 2), "differN_new_pca=2_N=2_w8_h8"),
+        "differN_new_conv": ((8, 2, 2), "differN_new_conv=2_N=2_w8_h8"),
+        "differN_old_conv": ((8, 2, 2), "differN_old_conv=2_N=2_w8_h8"),
+        "QIDDM_CL_new": ((64, 4, 2, 1), "QIDDM_CL_new_q=4_L=2_N=1"),
+        "QIDDM_CL_old": ((64, 4, 2, 1), "QIDDM_CL_old_q=4_L=2_N=1"),
+        "QIDDM_PL_old": ((64, 4, 2, 1), "QIDDM_PL_old_q=4_L=2_N=1"),
+        "QIDDM_PL": ((64, 4, 2, 1), "QIDDM_PL=4_L=2_N=1"),
+        "QIDDM_PL_noise": ((64, 4, 2, 1), "QIDDM_PL_noise=4_L=2_N=1"),
+        "QIDDM_LL_relu_noise": ((64, 4, 2, 1), "QIDDM_LL_noise=4_L=2_N=1"),
+        "QIDDM_LL_noise": ((64, 4, 2, 1), "QIDDM_LL_noise=4_L=2_N=1"),
+        "QIDDM_PP_noise": ((64, 4, 2, 1), "QIDDM_PP_noise=4_L=2_N=1"),
+        "QIDDM_PP_old": ((64, 4, 2, 1), "QIDDM_PP_features=4_L=2_N=1"),
+        "QIDDM_LL_old": ((64, 4, 2, 1), "QIDDM_linear_features=4_L=2_N=1"),
+        "QIDDM_bias_false": ((64, 4, 2, 1), "QIDDM_linear_features=4_L=2_N=1"),
+        "QIDDM_L_B": ((64, 4, 2, 1), "QIDDM_linear_batch_features=4_L=2_N=1"),
+        "QIDDM_A_differN_basePL": ((8, 2, 2), "QIDDM_pca_features=6_L=2_N=2"),
+        "QIDDM_A_sameN": ((8, 2, 2), "QIDDM_A_sameN=2_N=2_w8_h8"),
+        "QIDDM_A_differN_NEW": ((8, 2, 2), "QIDDM_pca_new=6_L=2_N=2"),
+    }
+    assert len(expect) == 27
+    for name, (args, save) in expect.items():
+        m = getattr(nn, name)(*args)
+        assert m.save_name() == save, name
+        assert isinstance(repr(m), str)
+    assert tuple(nn.QIDDM_bias_false(64, 4, 2, 1).weights1.shape) == (1, 2, 3, 4, 3)
+    assert tuple(nn.QIDDM_A_sameN(8, 2, 2).weights.shape) == (2, 2, 6, 3)
+    assert nn.QIDDM_bias_false(64, 4, 2, 1).linear_down.bias is None
