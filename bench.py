@@ -9,8 +9,10 @@ samples are independent): BASELINE configs[1] = MNIST 28x2
 qdense ``QNN_noise(784, 8, 14)`` (reference default model, src/mnist_exm.py:48), batch 256 per
 GPU.  One step = one body of ``Diffusion.sample`` (reference src/models.py:127-134):
 ``x <- net(x)`` on a resident (256, 1, 28, 28) float64 batch, i.e.
-linear_down -> [RZ encoders + 14 x (8 Rot + 8 CZ) + <Z>] -> linear_up, one fused launch
-(qiddm_dense_forward).  Synthetic
+linear_down -> [RZ encoders + 14 x (8 Rot + 8 CZ) + <Z>] -> linear_up; `--steps-per-graph` (10)
+consecutive steps of the sampling loop run in ONE launch of the fused sampler (qiddm_dense_sample:
+four wavefronts per sample, the image stays in registers between steps and every intermediate image
+is written out, as Diffusion.sample records it).  Synthetic
 random-noise images (``rand*0.75+0.5``, src/mnist_exm.py:396), random-init weights under
 ``torch.manual_seed(42)``.  The step is captured once into a hipGraph and replayed.
 
@@ -85,10 +87,7 @@ def make_runner(diff, x0, use_graph, steps_per_graph):
 
     def chunk(m):
         with torch.no_grad():
-            cur = x
-            for _ in range(m):
-                cur = diff.denoise_step(cur)
-            x.copy_(cur)
+            x.copy_(diff.denoise_steps(x, m)[-1])   # m loop bodies (one launch when the net fuses them)
 
     if not use_graph:
         def run_eager(k):
@@ -117,16 +116,16 @@ def make_runner(diff, x0, use_graph, steps_per_graph):
     return run, x
 
 
-def time_dominant_kernel(net, x_dev, launches=200):
-    """Average duration of the dominant kernel (dense_forward_kernel<float, 8>: linear_down +
-    circuit + linear_up of one denoise step) measured with HIP events on the stream it is launched
-    on: `launches` back-to-back launches inside one hipGraph replay, same arguments as in the
-    timed step."""
-    circ = net._circuit_descriptor()
+def time_dominant_kernel(diff, x_dev, steps_per_launch, launches=100):
+    """Average duration of the dominant kernel -- the fused sampler `dense_quad_kernel<float, 8, 4>`
+    running `steps_per_launch` denoise steps per launch, exactly the launch of the timed region --
+    measured with HIP events on the stream it is launched on: `launches` back-to-back launches
+    inside one hipGraph replay."""
+    circ = diff.net._circuit_descriptor()
 
     def once():
         with torch.no_grad():
-            return net(x_dev)
+            return diff.denoise_steps(x_dev, steps_per_launch)
 
     once()
     torch.cuda.synchronize()
@@ -283,9 +282,10 @@ def main():
     value = images / elapsed
     result = None
     if rank == 0:
-        kern_us, circ = time_dominant_kernel(diff.net, x0.to(dev))
+        spl = 1 if args.no_graph else args.steps_per_graph
+        kern_us, circ = time_dominant_kernel(diff, x0.to(dev), spl)
         g_per_sample = circ.gate_count()
-        alg_bytes = circ.algorithmic_bytes_per_sample("f32") * args.batch      # per launch
+        alg_bytes = circ.algorithmic_bytes_per_sample("f32") * args.batch * spl   # per launch
         achieved = alg_bytes / (kern_us * 1e-6) / 1e9
         result = {
             "metric": "denoise-step images/sec, 8-qubit MNIST-28",
@@ -310,13 +310,15 @@ def main():
             "gate_apps_per_s": value * g_per_sample,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_pmc_traffic("dense_forward_kernel<float, 8,", args.batch),
-                         "kernel": "qiddm::dense_forward_kernel<float, 8>",
+                         "traffic": load_pmc_traffic("dense_quad_kernel<float, 8, 4>", args.batch),
+                         "kernel": "qiddm::dense_quad_kernel<float, 8, 4>",
+                         "steps_per_launch": spl,
                          "kernel_avg_us": kern_us,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "note": "algorithmic = (G+1/2)*16*2^n B per sample (SURVEY 8d) x batch; the slab "
-                                 "lives in registers, so physical HBM traffic is images in/out + weights; "
-                                 "the kernel also does linear_down/linear_up of the step"},
+                         "note": "algorithmic = (G+1/2)*16*2^n B per sample (SURVEY 8d) x batch x steps per "
+                                 "launch; the slab lives in registers (4 wavefronts per sample), so physical "
+                                 "HBM traffic is the first image in + one image out per step; the kernel also "
+                                 "does linear_down/linear_up of every step"},
         }
         if not args.no_secondary and world == 1:
             result["secondary"] = secondary_measurements(dev, args.batch)

@@ -197,6 +197,22 @@ int qiddm_dense_forward(const qiddm_circuit_t *circ, const double *x, int64_t ba
                         int64_t out_features, int32_t post_mode, double noise_factor, double *y,
                         int64_t y_ld, void *stream);
 
+/* ---- fused sampling loop -----------------------------------------------------------------
+ * `n_steps` consecutive bodies of the reference's sampling loop (src/models.py:124-136)
+ *     x <- net(x)                                        (post_mode 0, "data" goal)
+ *     x <- clamp(x - (net(x) - 0.5) * 0.1 * noise_factor, 0, 1)   (post_mode 1, "noise" goal)
+ * in ONE launch, net = linear_down -> circuit rounds -> linear_up as in qiddm_dense_forward.
+ * y: (n_steps, batch, out_features) float64, y[s] = the image after step s+1 (row stride y_ld,
+ * step stride y_step_stride).  n_steps > 1 needs out_features == in_features.  Four wavefronts own
+ * one sample (qsim_quad.h): supported for 8 <= n_qubits <= 10, QIDDM_IMP_CZ, QIDDM_ENC_RZ,
+ * QIDDM_MEAS_EXPZ, features <= 2048; anything else returns QIDDM_ERR_UNSUPPORTED (loop over
+ * qiddm_dense_forward instead).                                                               */
+int qiddm_dense_sample(const qiddm_circuit_t *circ, const double *x, int64_t batch, int64_t x_ld,
+                       int64_t in_features, const double *w_down, const double *b_down,
+                       const double *angles, const double *w_up, const double *b_up,
+                       int64_t out_features, int32_t post_mode, double noise_factor, int32_t n_steps,
+                       double *y, int64_t y_ld, int64_t y_step_stride, void *stream);
+
 /* ---- fused quantum convolution -------------------------------------------------------
  * Replaces the (intended, SURVEY finding F3) forward of the reference's exported QConv2d
  * (`_QConv2d_FAST`, nn/qconv.py:51-87) in one launch:

@@ -40,6 +40,7 @@ EXPORTS = (
     "qiddm_adjoint_partials",
     "qiddm_backward_adjoint",
     "qiddm_dense_forward",
+    "qiddm_dense_sample",
     "qiddm_qconv_forward",
 )
 
@@ -99,6 +100,9 @@ def _declare(lib):
     lib.qiddm_dense_forward.restype = ctypes.c_int
     lib.qiddm_dense_forward.argtypes = [P, vp, i64, i64, i64, vp, vp, vp, vp, vp, i64, ctypes.c_int32,
                                         ctypes.c_double, vp, i64, vp]
+    lib.qiddm_dense_sample.restype = ctypes.c_int
+    lib.qiddm_dense_sample.argtypes = [P, vp, i64, i64, i64, vp, vp, vp, vp, vp, i64, ctypes.c_int32,
+                                       ctypes.c_double, ctypes.c_int32, vp, i64, i64, vp]
     lib.qiddm_adjoint_partials.restype = i64
     lib.qiddm_adjoint_partials.argtypes = [P, i64]
     lib.qiddm_backward_adjoint.restype = ctypes.c_int

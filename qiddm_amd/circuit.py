@@ -234,6 +234,29 @@ def dense_forward(circ: Circuit, x: torch.Tensor, w_down, b_down, angles, w_up, 
     return y
 
 
+def dense_sample(circ: Circuit, x: torch.Tensor, w_down, b_down, angles, w_up, b_up, n_steps: int,
+                 precision: str | None = None, post_mode: int = 0, noise_factor: float = 1.0):
+    """``n_steps`` consecutive bodies of the sampling loop in ONE launch (``qiddm_dense_sample``).
+    Returns (n_steps, batch, features) float64 -- the image after every step.  Raises ``QiddmError``
+    (status -2) when the configuration is outside the fused sampler's range."""
+    precision = precision or _default_precision
+    _require_device(angles, "the circuit weights")
+    _require_device(x, "the input batch")
+    device = angles.device
+    xx = _as_f64(x, device)
+    wd, bd, wu, bu, ang = (_as_f64(t, device) for t in (w_down, b_down, w_up, b_up, angles))
+    if tuple(ang.shape) != circ.angles_shape:
+        raise ValueError(f"angles must have shape {circ.angles_shape}; got {tuple(ang.shape)}")
+    y = torch.empty(n_steps, xx.shape[0], wu.shape[0], dtype=torch.float64, device=device)
+    cs = circ.c_struct(precision)
+    _capi.check(_capi.lib().qiddm_dense_sample(
+        ctypes.byref(cs), xx.data_ptr(), xx.shape[0], xx.stride(0), xx.shape[1], wd.data_ptr(),
+        0 if bd is None else bd.data_ptr(), ang.data_ptr(), wu.data_ptr(), 0 if bu is None else bu.data_ptr(),
+        wu.shape[0], int(post_mode), float(noise_factor), int(n_steps), y.data_ptr(), y.stride(1),
+        y.stride(0), _stream_ptr(device)))
+    return y
+
+
 def qconv_forward(x: torch.Tensor, angles: torch.Tensor, n_qubits: int, out_channels: int, kernel_size,
                   padding, precision: str | None = None) -> torch.Tensor:
     """The intended QConv2d forward in one launch (``qiddm_qconv_forward``); no autograd.

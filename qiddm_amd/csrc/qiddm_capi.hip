@@ -13,6 +13,7 @@
 #include "qsim_fused.h"
 #include "qsim_tiled.h"
 #include "qsim_adjoint.h"
+#include "qsim_quad.h"
 
 namespace {
 
@@ -248,6 +249,53 @@ int dispatch_qconv(int n, const double* x, const double* angles, double* y, cons
     case 9: return launch_qconv<T, 9>(x, angles, y, cv, p, st);
     case 10: return launch_qconv<T, 10>(x, angles, y, cv, p, st);
     default: return fail(QIDDM_ERR_UNSUPPORTED, "fused QConv2d needs n_qubits <= 10 (got %d)", n);
+  }
+}
+
+// ---- quad layout (4 waves per sample) dense sampler ---------------------------------------------------
+bool quad_supported(const qiddm_circuit_t* c, int64_t in_features, int64_t out_features) {
+  return c->n_qubits >= 8 && c->n_qubits <= 10 && c->imprimitive == QIDDM_IMP_CZ &&
+         c->encoding == QIDDM_ENC_RZ && c->measure == QIDDM_MEAS_EXPZ && in_features <= 2048 &&
+         out_features <= 2048 && c->n_qubits > 1;
+}
+
+template <typename T, int N>
+int launch_quad(const double* x, const double* wd, const double* bd, const double* angles, const double* wu,
+                const double* bu, double* y, const qiddm::QuadScalars& d, const qiddm::KScalars& p,
+                hipStream_t stream) {
+  if (p.batch == 0 || d.n_steps == 0) return QIDDM_OK;
+  const int64_t n_rot = (int64_t)p.n_rounds * p.n_blocks * p.sel_layers * N;
+  const size_t smem = qiddm::QuadSmem<T, N>::bytes(n_rot);
+  if (smem > kMaxLds)
+    return fail(QIDDM_ERR_UNSUPPORTED, "circuit with %lld Rot gates needs %zu B of LDS (limit %zu)",
+                (long long)n_rot, smem, kMaxLds);
+  const bool small = d.in_features <= 1024 && d.out_features <= 1024;
+  auto kern = small ? qiddm::dense_quad_kernel<T, N, 4> : qiddm::dense_quad_kernel<T, N, 8>;
+  static bool big_lds_enabled[2] = {false, false};
+  if (smem > 48 * 1024 && !big_lds_enabled[small]) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    if (ea != hipSuccess)
+      return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
+    big_lds_enabled[small] = true;
+  }
+  const unsigned blocks = (unsigned)(p.batch < 2048 ? p.batch : 2048);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, stream, x, wd, bd, angles, wu, bu, y, d, p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return fail(QIDDM_ERR_LAUNCH, "dense_quad_kernel<n=%d> launch failed: %s", N, hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
+template <typename T>
+int dispatch_quad(int n, const double* x, const double* wd, const double* bd, const double* angles,
+                  const double* wu, const double* bu, double* y, const qiddm::QuadScalars& d,
+                  const qiddm::KScalars& p, hipStream_t st) {
+  switch (n) {
+    case 8: return launch_quad<T, 8>(x, wd, bd, angles, wu, bu, y, d, p, st);
+    case 9: return launch_quad<T, 9>(x, wd, bd, angles, wu, bu, y, d, p, st);
+    case 10: return launch_quad<T, 10>(x, wd, bd, angles, wu, bu, y, d, p, st);
+    default: return fail(QIDDM_ERR_UNSUPPORTED, "quad layout needs 8 <= n <= 10 (got %d)", n);
   }
 }
 
@@ -624,6 +672,10 @@ int qiddm_dense_forward(const qiddm_circuit_t* c, const double* x, int64_t batch
   if (x == y) return fail(QIDDM_ERR_INVALID, "y must not alias x");
   if (x_ld < in_features || y_ld < out_features)
     return fail(QIDDM_ERR_INVALID, "row strides smaller than the feature counts");
+  static const bool no_quad = std::getenv("QIDDM_NO_QUAD") != nullptr;  // tuning switch
+  if (!no_quad && batch <= 1024 && quad_supported(c, in_features, out_features))
+    return qiddm_dense_sample(c, x, batch, x_ld, in_features, w_down, b_down, angles, w_up, b_up, out_features,
+                              post_mode, noise_factor, 1, y, y_ld, batch * y_ld, stream);
   qiddm::KScalars p = make_params(c);
   p.batch = batch;
   qiddm::DenseScalars d;
@@ -683,6 +735,45 @@ int qiddm_qconv_forward(const qiddm_circuit_t* c, const double* x, int64_t batch
   hipStream_t st = static_cast<hipStream_t>(stream);
   return c->dtype == QIDDM_F32 ? dispatch_qconv<float>(c->n_qubits, x, angles, y, cv, p, st)
                                : dispatch_qconv<double>(c->n_qubits, x, angles, y, cv, p, st);
+}
+
+int qiddm_dense_sample(const qiddm_circuit_t* c, const double* x, int64_t batch, int64_t x_ld,
+                       int64_t in_features, const double* w_down, const double* b_down,
+                       const double* angles, const double* w_up, const double* b_up, int64_t out_features,
+                       int32_t post_mode, double noise_factor, int32_t n_steps, double* y, int64_t y_ld,
+                       int64_t y_step_stride, void* stream) {
+  int rc = check_circuit(c);
+  if (rc != QIDDM_OK) return rc;
+  if (batch < 0 || n_steps < 0) return fail(QIDDM_ERR_INVALID, "negative batch / n_steps");
+  if (in_features < 1 || out_features < 1) return fail(QIDDM_ERR_INVALID, "bad feature counts");
+  if (!quad_supported(c, in_features, out_features))
+    return fail(QIDDM_ERR_UNSUPPORTED, "fused sampling loop: needs 8 <= n <= 10, CZ, RZ encoding, <Z>, "
+                "features <= 2048");
+  if (post_mode != 0 && post_mode != 1) return fail(QIDDM_ERR_INVALID, "post_mode must be 0 or 1");
+  if ((post_mode == 1 || n_steps > 1) && in_features != out_features)
+    return fail(QIDDM_ERR_INVALID, "chained steps / post_mode 1 need out_features == in_features");
+  if (batch == 0 || n_steps == 0) return QIDDM_OK;
+  if (!x || !w_down || !angles || !w_up || !y) return fail(QIDDM_ERR_INVALID, "x/w_down/angles/w_up/y is NULL");
+  if (x == y) return fail(QIDDM_ERR_INVALID, "y must not alias x");
+  if (x_ld < in_features || y_ld < out_features || y_step_stride < batch * y_ld - (y_ld - out_features))
+    return fail(QIDDM_ERR_INVALID, "strides smaller than the tensor extents");
+  qiddm::KScalars p = make_params(c);
+  p.batch = batch;
+  qiddm::QuadScalars d;
+  std::memset(&d, 0, sizeof(d));
+  d.x_ld = x_ld;
+  d.y_ld = y_ld;
+  d.y_step_stride = y_step_stride;
+  d.in_features = (int32_t)in_features;
+  d.out_features = (int32_t)out_features;
+  d.post_mode = post_mode;
+  d.n_steps = n_steps;
+  d.noise_factor = noise_factor;
+  if (const char* e = std::getenv("QIDDM_STAMP_PTR")) d.stamps = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 0));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return c->dtype == QIDDM_F32
+             ? dispatch_quad<float>(c->n_qubits, x, w_down, b_down, angles, w_up, b_up, y, d, p, st)
+             : dispatch_quad<double>(c->n_qubits, x, w_down, b_down, angles, w_up, b_up, y, d, p, st);
 }
 
 }  // extern "C"

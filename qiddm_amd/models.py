@@ -76,6 +76,20 @@ class Diffusion(torch.nn.Module):
             return predicted
         return torch.clamp(x - (predicted - 0.5) * 0.1 * noise_factor, 0, 1)
 
+    def denoise_steps(self, x, n, noise_factor=1.0):
+        """``n`` consecutive loop bodies; returns the (n, *x.shape) stack of the images after each one.
+        Nets that own a fused sampler (``fused_sample_steps``) run all n in one launch."""
+        fused = getattr(self.net, "fused_sample_steps", None)
+        if fused is not None and not torch.is_grad_enabled() and n > 0:
+            out = fused(x, n, self.prediction_goal, noise_factor)
+            if out is not None:
+                return out
+        outs, cur = [], x
+        for _ in range(n):
+            cur = self.denoise_step(cur, noise_factor)
+            outs.append(cur)
+        return torch.stack(outs) if outs else x.new_empty((0,) + tuple(x.shape))
+
     def sample(self, n_iters, first_x=None, labels=None, show_progress: bool = False,
                only_last=False, step=1, noise_factor=1.0) -> torch.Tensor:
         if first_x is None:
@@ -85,11 +99,15 @@ class Diffusion(torch.nn.Module):
         if show_progress and tqdm is not None:
             iters = tqdm.tqdm(iters)
         with torch.no_grad():
-            x = first_x
-            for i in iters:
-                x = self.denoise_step(x, noise_factor)
-                if i % step == 0:
-                    outp.append(x)
+            if not (show_progress and tqdm is not None):
+                steps = self.denoise_steps(first_x, n_iters, noise_factor)
+                outp += [steps[i] for i in range(n_iters) if i % step == 0]
+            else:
+                x = first_x
+                for i in iters:
+                    x = self.denoise_step(x, noise_factor)
+                    if i % step == 0:
+                        outp.append(x)
         if only_last:
             return outp[-1]
         st = torch.stack(outp)                                  # iters batch 1 height width

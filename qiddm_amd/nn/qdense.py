@@ -239,6 +239,21 @@ class QNN_noise(_QuantumNet):
         ev = ev.to(torch.double)
         return self.linear_up(ev).view(b, c, w, h)
 
+    def fused_sample_steps(self, x, n_steps, goal, noise_factor=1.0):
+        """n_steps bodies of Diffusion.sample in one launch; None when not applicable."""
+        if not (self._fused_rounds_ok() and 8 <= self.hidden_features <= 10):
+            return None
+        b, c, w, h = x.shape
+        circ = self._circuit_descriptor()
+        flat = x.reshape(b, -1).to(self.linear_down.weight.device).to(torch.double)
+        if flat.shape[1] > 2048 or flat.shape[1] != self.linear_up.weight.shape[0]:
+            return None
+        out = _c.dense_sample(circ, flat, self.linear_down.weight, self.linear_down.bias,
+                              self.weights.reshape(circ.angles_shape), self.linear_up.weight,
+                              self.linear_up.bias, n_steps, post_mode=0 if goal == "data" else 1,
+                              noise_factor=noise_factor)
+        return out.view(n_steps, b, c, w, h)
+
     def __repr__(self):
         return f"QNN(qdepth={self.qdepth}, features={self.hidden_features}, add_noise={self.add_noise})"
 
@@ -415,6 +430,22 @@ class _QIDDMBase(_QuantumNet):
             x = self.qnode(x, self.weights1[n])
             x = (x.detach() if self.detach_quantum else x).to(torch.float64)   # finding F1
         return x
+
+    def fused_sample_steps(self, x, n_steps, goal, noise_factor=1.0):
+        """n_steps bodies of Diffusion.sample in one launch; None when not applicable."""
+        if not (self._fused_rounds_ok() and not self._use_pca and hasattr(self, "linear_down")
+                and 8 <= self.hidden_features <= 10 and type(self)._circuit is _QIDDMBase._circuit):
+            return None
+        b, c, w, h = x.shape
+        flat = x.reshape(b, -1)
+        if flat.shape[1] > 2048 or flat.shape[1] != self.linear_up.weight.shape[0]:
+            return None
+        circ = _c.Circuit(n_qubits=self.hidden_features, encoding="rz", imprimitive="CZ", measure="expz",
+                          n_rounds=self.N, n_blocks=self.spectrum_layer, sel_layers=2)
+        out = _c.dense_sample(circ, flat, self.linear_down.weight, self.linear_down.bias, self.weights1,
+                              self.linear_up.weight, self.linear_up.bias, n_steps,
+                              post_mode=0 if goal == "data" else 1, noise_factor=noise_factor)
+        return out.to(self.linear_up.weight.dtype).view(n_steps, b, c, w, h)
 
     def forward(self, x):
         b, c, w, h = x.shape

@@ -291,3 +291,67 @@ def test_qconv2d_fused_equals_traced_path(cin, cout, k, pad, hw):
     assert fused.shape == traced.shape == ref.shape
     assert torch.allclose(fused, ref, atol=1e-3), (fused - ref).abs().max()
     assert torch.allclose(fused, traced, atol=1e-4), (fused - traced).abs().max()
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("f64", 1e-9)])
+@pytest.mark.parametrize("n,N,L,S,P", [(8, 1, 1, 14, 784), (8, 2, 6, 2, 784), (9, 2, 2, 2, 300), (10, 1, 3, 2, 100)])
+def test_dense_sample_quad_kernel(n, N, L, S, P, precision, tol):
+    """qiddm_dense_sample: four wavefronts per sample, several sampling-loop bodies in one launch."""
+    from qiddm_amd.circuit import Circuit, dense_sample
+    g = torch.Generator().manual_seed(n * 10 + P)
+    B, steps = 7, 3
+    x = torch.rand(B, P, generator=g, dtype=torch.float64)
+    wd = torch.randn(n, P, generator=g, dtype=torch.float64) / P ** 0.5 * 3
+    bd = torch.randn(n, generator=g, dtype=torch.float64)
+    wu = torch.randn(P, n, generator=g, dtype=torch.float64) * 0.3
+    bu = torch.rand(P, generator=g, dtype=torch.float64)
+    w = torch.randn(N, L, S, n, 3, generator=g, dtype=torch.float64) * 0.6
+    circ = Circuit(n_qubits=n, encoding="rz", imprimitive="CZ", measure="expz", n_rounds=N, n_blocks=L, sel_layers=S)
+    spec = oc.Spec(n=n, encoding="rz", imprimitive="CZ", measure="expz")
+    net = lambda t: oc.run_circuit(spec, t @ wd.T + bd, w) @ wu.T + bu
+    dev = lambda t: t.to(DEV)
+    for post in (0, 1):
+        got = dense_sample(circ, dev(x), dev(wd), dev(bd), dev(w), dev(wu), dev(bu), steps, precision,
+                           post_mode=post, noise_factor=0.8).cpu()
+        cur, refs = x, []
+        for _ in range(steps):
+            cur = net(cur) if post == 0 else torch.clamp(cur - (net(cur) - 0.5) * 0.1 * 0.8, 0, 1)
+            refs.append(cur)
+        ref = torch.stack(refs)
+        assert got.shape == ref.shape
+        assert torch.allclose(got, ref, atol=tol, rtol=tol), (post, (got - ref).abs().max())
+
+
+def test_dense_forward_large_batch_uses_wave_kernel():
+    """Above 1024 samples qiddm_dense_forward runs the one-wave-per-sample kernel (LDS-staged weights)."""
+    from qiddm_amd.circuit import Circuit, dense_forward
+    g = torch.Generator().manual_seed(3)
+    n, P, B = 8, 784, 2100
+    x = torch.rand(B, P, generator=g, dtype=torch.float64)
+    wd = torch.randn(n, P, generator=g, dtype=torch.float64) * 0.1
+    wu = torch.randn(P, n, generator=g, dtype=torch.float64)
+    w = torch.randn(1, 2, 2, n, 3, generator=g, dtype=torch.float64) * 0.6
+    circ = Circuit(n_qubits=n, encoding="rz", imprimitive="CZ", measure="expz", n_blocks=2, sel_layers=2)
+    got = dense_forward(circ, x.to(DEV), wd.to(DEV), None, w.to(DEV), wu.to(DEV), None, "f32").cpu()
+    ref = oc.run_circuit(oc.Spec(n=n, encoding="rz", imprimitive="CZ", measure="expz"), x @ wd.T, w) @ wu.T
+    assert torch.allclose(got, ref, atol=1e-4, rtol=1e-4), (got - ref).abs().max()
+
+
+def test_diffusion_sample_uses_fused_steps():
+    """Diffusion.sample through the fused sampler == the step-by-step loop == the oracle loop."""
+    from qiddm_amd import models, nn, noise
+    for goal in ("data", "noise"):
+        torch.manual_seed(14)
+        net = nn.QIDDM_LL_noise(784, 8, 3, 2)
+        diff = models.Diffusion(net, noise.add_normal_noise_multiple, goal, (28, 28)).to(DEV, dtype=torch.double).eval()
+        x = (_img(6, 28, 15) * 0.75 + 0.5).to(DEV)
+        mosaic = diff.sample(first_x=x, n_iters=4)
+        with torch.no_grad():
+            cur, outs = x, [x]
+            for _ in range(4):
+                cur = diff.denoise_step(cur)
+                outs.append(cur)
+        st = torch.stack(outs)
+        ref = st[:, :, 0].permute(0, 2, 1, 3).reshape(5 * 28, 6 * 28)
+        assert mosaic.shape == ref.shape
+        assert torch.allclose(mosaic, ref, atol=1e-4), (goal, (mosaic - ref).abs().max())
