@@ -1,6 +1,7 @@
-"""UNet glue around the quantum convolutions (reference nn/unet.py).  Everything here is
-classical PyTorch-ROCm (BatchNorm / MaxPool / bilinear Upsample / concat stay on
-MIOpen / rocBLAS through torch); only ``Conv2d(qdepth > 0)`` reaches the HIP engine."""
+"""UNet glue around the quantum convolutions (reference nn/unet.py).  Everything here is classical
+PyTorch-ROCm (BatchNorm / MaxPool / bilinear Upsample / concat stay on MIOpen / rocBLAS through torch);
+only ``Conv2d(qdepth > 0)`` reaches the HIP engine.  Module attribute names and Sequential positions
+match the reference so that its checkpoints (``net.down_blocks.0.net.0.weight`` ...) load unchanged."""
 from __future__ import annotations
 
 import torch
@@ -8,103 +9,88 @@ import torch
 from .qconv import QConv2d
 from .utils import autopad, get_label_embedding
 
+F64 = torch.double
+
 
 def Conv2d(**kwargs):
     """``qdepth > 0`` -> :class:`QConv2d`, else ``torch.nn.Conv2d(...).double()``
     (reference nn/unet.py:9-24; default qdepth 3)."""
     qdepth = kwargs.pop("qdepth", 3)
-    if qdepth > 0:
-        return QConv2d(qdepth=qdepth, **kwargs)
-    return torch.nn.Conv2d(**kwargs).double()
+    return QConv2d(qdepth=qdepth, **kwargs) if qdepth > 0 else torch.nn.Conv2d(**kwargs).to(F64)
 
 
-def _bn(ch):
-    return torch.nn.BatchNorm2d(ch, dtype=torch.double)
+def _conv3(c_in, c_out, k, qdepth):
+    return Conv2d(in_channels=c_in, out_channels=c_out, kernel_size=k, padding=1, qdepth=qdepth)
 
 
 class UpBlock(torch.nn.Module):
-    """Reference nn/unet.py:28-75."""
+    """Reference nn/unet.py:28-75.  ``up_conv`` = [Upsample, 1x1 conv];
+    ``net`` = [conv, ReLU, BN, conv, BN, ReLU] (that order, as in the reference)."""
 
     def __init__(self, in_channels, out_channels, kernel_size=3, qdepth=3):
         super().__init__()
         self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
-        self.up_conv = torch.nn.Sequential(
-            torch.nn.Upsample(scale_factor=2, mode="bilinear"),
-            Conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=1, padding=0, qdepth=qdepth),
-        ).double()
+        one_by_one = Conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=1, padding=0, qdepth=qdepth)
+        self.up_conv = torch.nn.Sequential(torch.nn.Upsample(scale_factor=2, mode="bilinear"), one_by_one).to(F64)
         self.net = torch.nn.Sequential(
-            Conv2d(in_channels=2 * out_channels, out_channels=out_channels, kernel_size=kernel_size,
-                   padding=1, qdepth=qdepth),
-            torch.nn.ReLU(),
-            _bn(out_channels),
-            Conv2d(in_channels=out_channels, out_channels=out_channels, kernel_size=kernel_size,
-                   padding=1, qdepth=qdepth),
-            _bn(out_channels),
-            torch.nn.ReLU(),
-        ).double()
+            _conv3(2 * out_channels, out_channels, kernel_size, qdepth), torch.nn.ReLU(),
+            torch.nn.BatchNorm2d(out_channels, dtype=F64),
+            _conv3(out_channels, out_channels, kernel_size, qdepth),
+            torch.nn.BatchNorm2d(out_channels, dtype=F64), torch.nn.ReLU(),
+        ).to(F64)
 
     def forward(self, from_down, from_up):
-        from_up = self.up_conv(from_up)
-        from_down, from_up = autopad(from_down.double(), from_up.double())
-        return self.net(torch.cat([from_up, from_down], dim=1).double())
+        skip, up = autopad(from_down.to(F64), self.up_conv(from_up).to(F64))
+        return self.net(torch.cat([up, skip], dim=1).to(F64))
 
 
 class DownBlock(torch.nn.Module):
-    """Reference nn/unet.py:78-116."""
+    """Reference nn/unet.py:78-116.  ``net`` = [conv, BN, ReLU, conv, BN, ReLU]; returns
+    (pooled, before_pool)."""
 
     def __init__(self, in_channels, out_channels, pooling, kernel_size=3, qdepth=3):
         super().__init__()
         self.in_channels, self.out_channels = in_channels, out_channels
         self.kernel_size, self.pooling = kernel_size, pooling
         self.net = torch.nn.Sequential(
-            Conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=kernel_size,
-                   qdepth=qdepth, padding=1),
-            _bn(out_channels),
-            torch.nn.ReLU(),
-            Conv2d(in_channels=out_channels, out_channels=out_channels, kernel_size=kernel_size,
-                   qdepth=qdepth, padding=1),
-            _bn(out_channels),
-            torch.nn.ReLU(),
-        ).double()
-        if self.pooling:
+            _conv3(in_channels, out_channels, kernel_size, qdepth),
+            torch.nn.BatchNorm2d(out_channels, dtype=F64), torch.nn.ReLU(),
+            _conv3(out_channels, out_channels, kernel_size, qdepth),
+            torch.nn.BatchNorm2d(out_channels, dtype=F64), torch.nn.ReLU(),
+        ).to(F64)
+        if pooling:
             self.pooling_layer = torch.nn.MaxPool2d(kernel_size=2, stride=2)
 
     def forward(self, x):
-        before_pool = self.net(x.double())
-        x = self.pooling_layer(before_pool) if self.pooling else before_pool
-        return x, before_pool
+        before_pool = self.net(x.to(F64))
+        return (self.pooling_layer(before_pool) if self.pooling else before_pool), before_pool
 
 
 class UNetUndirected(torch.nn.Module):
-    """Reference nn/unet.py:119-180.  ``(depth=3, start_channels=8, qdepth=3)``."""
+    """Reference nn/unet.py:119-180.  ``(depth=3, start_channels=8, qdepth=3)``: channels
+    start, 2*start, ... on the way down, halved on the way up, 1x1 ``final_conv`` to one channel."""
 
     def __init__(self, depth=3, start_channels=8, qdepth=3):
         super().__init__()
         self.depth, self.start_channels, self.qdepth = depth, start_channels, qdepth
         assert self.depth > 0, "Depth must be greater than 0"
-        ch_out = -1
-        downs = []
-        for i in range(depth):
-            ch_in = 1 if i == 0 else ch_out
-            ch_out = start_channels * 2 ** i
-            downs.append(DownBlock(ch_in, ch_out, pooling=i < depth - 1, qdepth=qdepth))
-        ups = []
-        for _ in range(depth - 1):
-            ch_in, ch_out = ch_out, ch_out // 2
-            ups.append(UpBlock(ch_in, ch_out, qdepth=qdepth))
-        self.down_blocks = torch.nn.ModuleList(downs).double()
-        self.up_blocks = torch.nn.ModuleList(ups).double()
-        self.final_conv = Conv2d(in_channels=ch_out, out_channels=1, kernel_size=1, padding=0,
-                                 qdepth=qdepth).double()
+        widths = [start_channels * 2 ** i for i in range(depth)]
+        downs = [DownBlock(1 if i == 0 else widths[i - 1], widths[i], pooling=i < depth - 1, qdepth=qdepth)
+                 for i in range(depth)]
+        ups = [UpBlock(widths[i], widths[i] // 2, qdepth=qdepth) for i in range(depth - 1, 0, -1)]
+        self.down_blocks = torch.nn.ModuleList(downs).to(F64)
+        self.up_blocks = torch.nn.ModuleList(ups).to(F64)
+        last = widths[0] if depth > 1 else widths[-1]
+        self.final_conv = Conv2d(in_channels=last, out_channels=1, kernel_size=1, padding=0, qdepth=qdepth).to(F64)
 
     def forward(self, x):
+        x = x.to(F64)
         skips = []
-        x = x.double()
         for block in self.down_blocks:
             x, before_pool = block(x)
             skips.append(before_pool)
         for i, block in enumerate(self.up_blocks):
-            x = block(skips[-(i + 2)].double(), x.double())
+            x = block(skips[-(i + 2)].to(F64), x.to(F64))
         return self.final_conv(x)
 
     def extra_repr(self) -> str:
@@ -118,8 +104,7 @@ class UnetDirected(UNetUndirected):
     """Label-conditioned variant (reference nn/unet.py:183-190)."""
 
     def forward(self, x, y):
-        mask = get_label_embedding(y.double(), x.shape[2], x.shape[3])
-        return super().forward(x.double() + mask)
+        return super().forward(x.to(F64) + get_label_embedding(y.to(F64), x.shape[2], x.shape[3]))
 
     def save_name(self) -> str:
         return f"unet_directed_d{self.depth}_s{self.start_channels}_d{self.qdepth}"

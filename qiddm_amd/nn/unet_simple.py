@@ -1,4 +1,8 @@
-""""Simple" UNet: every block is one QConv2d + BatchNorm2d (reference nn/unet_simple.py)."""
+""""Simple" UNet: every block is one QConv2d + BatchNorm2d (reference nn/unet_simple.py).
+
+Same class names, constructor orders, attribute names (``net``, ``up_conv``, ``down_blocks``,
+``up_blocks``, ``final_conv``) and ``save_name()`` strings as the reference, so its ``state_dict`` keys
+line up; the layers themselves are assembled by the two helpers below."""
 from __future__ import annotations
 
 import torch
@@ -8,59 +12,55 @@ from .unet import DownBlock, UNetUndirected, UpBlock
 from .utils import get_label_embedding
 
 
+def _qconv_then_bn(c_in: int, c_out: int, k, qdepth: int) -> torch.nn.Sequential:
+    """[QConv2d(k, pad 1), BatchNorm2d] -- indices 0 and 1 of every ``net`` (reference :9-18, :30-39)."""
+    conv = QConv2d(in_channels=c_in, out_channels=c_out, kernel_size=k, padding=1, qdepth=qdepth)
+    return torch.nn.Sequential(conv, torch.nn.BatchNorm2d(c_out))
+
+
+def _upsample_then_qconv1x1(c_in: int, c_out: int, qdepth: int) -> torch.nn.Sequential:
+    """[bilinear x2, QConv2d(1x1)] -- the ``up_conv`` of an up block (reference :40-49)."""
+    conv = QConv2d(in_channels=c_in, out_channels=c_out, kernel_size=1, padding=0, qdepth=qdepth)
+    return torch.nn.Sequential(torch.nn.Upsample(scale_factor=2, mode="bilinear"), conv)
+
+
 class DownBlockS(DownBlock):
-    """Reference nn/unet_simple.py:6-18."""
+    """Reference nn/unet_simple.py:6-18 (the classical base is built first, then ``net`` is replaced)."""
 
     def __init__(self, in_channels, out_channels, pooling, kernel_size=3, qdepth=3):
         super().__init__(in_channels, out_channels, pooling, kernel_size, qdepth)
-        self.net = torch.nn.Sequential(
-            QConv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=kernel_size,
-                    qdepth=qdepth, padding=1),
-            torch.nn.BatchNorm2d(out_channels),
-        )
+        self.net = _qconv_then_bn(in_channels, out_channels, kernel_size, qdepth)
 
 
 class UpBlockS(UpBlock):
-    """Reference nn/unet_simple.py:21-49 (the base is built classically, qdepth=0, then
-    both sub-nets are replaced)."""
+    """Reference nn/unet_simple.py:21-49 (base built with qdepth=0, both sub-nets replaced)."""
 
     def __init__(self, in_channels, out_channels, kernel_size=3, qdepth=3):
         super().__init__(in_channels, out_channels, kernel_size, qdepth=0)
-        self.net = torch.nn.Sequential(
-            QConv2d(in_channels=2 * out_channels, out_channels=out_channels, kernel_size=kernel_size,
-                    padding=1, qdepth=qdepth),
-            torch.nn.BatchNorm2d(out_channels),
-        )
-        self.up_conv = torch.nn.Sequential(
-            torch.nn.Upsample(scale_factor=2, mode="bilinear"),
-            QConv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=1, padding=0,
-                    qdepth=qdepth),
-        )
+        self.net = _qconv_then_bn(2 * out_channels, out_channels, kernel_size, qdepth)
+        self.up_conv = _upsample_then_qconv1x1(in_channels, out_channels, qdepth)
 
 
 class UNetUndirectedS(UNetUndirected):
-    """Reference nn/unet_simple.py:52-84; ``final_conv`` stays the classical 1x1 conv of the
-    qdepth=0 base."""
+    """Reference nn/unet_simple.py:52-84; ``final_conv`` stays the classical 1x1 conv of the qdepth=0 base."""
 
     def __init__(self, depth=3, start_channels=8, qdepth=3):
         super().__init__(depth, start_channels, qdepth=0)
         self.qdepth = qdepth
-        self.down_blocks = torch.nn.ModuleList(
-            DownBlockS(db.in_channels, db.out_channels, db.pooling, db.kernel_size, qdepth)
-            for db in self.down_blocks)
-        self.up_blocks = torch.nn.ModuleList(
-            UpBlockS(ub.in_channels, ub.out_channels, ub.kernel_size, qdepth) for ub in self.up_blocks)
+        downs = [DownBlockS(b.in_channels, b.out_channels, b.pooling, b.kernel_size, qdepth) for b in self.down_blocks]
+        ups = [UpBlockS(b.in_channels, b.out_channels, b.kernel_size, qdepth) for b in self.up_blocks]
+        self.down_blocks = torch.nn.ModuleList(downs)
+        self.up_blocks = torch.nn.ModuleList(ups)
 
     def save_name(self) -> str:
         return f"unet_s_undirected_d{self.depth}_s{self.start_channels}_d{self.qdepth}"
 
 
 class UnetDirectedS(UNetUndirectedS):
-    """Reference nn/unet_simple.py:87-94."""
+    """Label-conditioned variant (reference nn/unet_simple.py:87-94)."""
 
     def forward(self, x, y):
-        mask = get_label_embedding(y, x.shape[2], x.shape[3])
-        return super().forward(x + mask)
+        return super().forward(x + get_label_embedding(y, x.shape[2], x.shape[3]))
 
     def save_name(self) -> str:
         return f"unet_s_directed_d{self.depth}_s{self.start_channels}_d{self.qdepth}"
