@@ -39,6 +39,7 @@ EXPORTS = (
     "qiddm_forward_shifted",
     "qiddm_adjoint_partials",
     "qiddm_backward_adjoint",
+    "qiddm_adjoint_finalize",
     "qiddm_dense_forward",
     "qiddm_dense_sample",
     "qiddm_qconv_forward",
@@ -107,6 +108,8 @@ def _declare(lib):
     lib.qiddm_adjoint_partials.argtypes = [P, i64]
     lib.qiddm_backward_adjoint.restype = ctypes.c_int
     lib.qiddm_backward_adjoint.argtypes = [P, vp, i64, i64, vp, vp, i64, vp, vp, i64, vp]
+    lib.qiddm_adjoint_finalize.restype = ctypes.c_int
+    lib.qiddm_adjoint_finalize.argtypes = [P, vp, vp, i64, vp, vp]
     lib.qiddm_qconv_forward.restype = ctypes.c_int
     lib.qiddm_qconv_forward.argtypes = [P, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, vp, vp]
 

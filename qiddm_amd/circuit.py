@@ -370,12 +370,10 @@ def run_adjoint(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch.Ten
     _capi.check(lib.qiddm_backward_adjoint(ctypes.byref(cs), x.data_ptr(), batch, ld, table.data_ptr(),
                                            g.data_ptr(), g.shape[1], kp.data_ptr(),
                                            0 if gin is None else gin.data_ptr(), gin_cols, _stream_ptr(device)))
-    k = kp.to(torch.float64).sum(dim=0)                                   # (G, 8)
-    kc = torch.complex(k[:, 0::2], k[:, 1::2]).reshape(n_rot, 2, 2)       # K_ab
-    with torch.enable_grad():
-        a = angles.detach().to(torch.float64).reshape(-1, 3).clone().requires_grad_(True)
-        proxy = 2.0 * (_rot_matrices(a) * kc).sum().real
-        (ga,) = torch.autograd.grad(proxy, a)
+    a64 = angles.detach().to(torch.float64).contiguous()
+    ga = torch.empty(n_rot, 3, dtype=torch.float64, device=device)
+    _capi.check(lib.qiddm_adjoint_finalize(ctypes.byref(cs), a64.data_ptr(), kp.data_ptr(), n_part,
+                                           ga.data_ptr(), _stream_ptr(device)))
     return ga.reshape(circ.angles_shape), (None if gin is None else gin.to(torch.float64))
 
 

@@ -647,6 +647,26 @@ int qiddm_backward_adjoint(const qiddm_circuit_t* c, const void* inputs, int64_t
                                : dispatch_adjoint<double>(c->n_qubits, ptr, k_partials, grad_inputs, p, ad, st);
 }
 
+int qiddm_adjoint_finalize(const qiddm_circuit_t* c, const double* angles, const void* k_partials,
+                           int64_t n_partials, double* grad_angles, void* stream) {
+  int rc = check_circuit(c);
+  if (rc != QIDDM_OK) return rc;
+  if (!angles || !k_partials || !grad_angles) return fail(QIDDM_ERR_INVALID, "angles/k_partials/grad_angles is NULL");
+  if (n_partials < 0) return fail(QIDDM_ERR_INVALID, "n_partials < 0");
+  const int64_t n_rot = (int64_t)c->n_rounds * c->n_blocks * c->sel_layers * c->n_qubits;
+  const unsigned blocks = (unsigned)((n_rot + 127) / 128);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (c->dtype == QIDDM_F32)
+    hipLaunchKernelGGL(qiddm::adjoint_finalize_kernel<float>, dim3(blocks), dim3(128), 0, st,
+                       static_cast<const float*>(k_partials), n_partials, n_rot, angles, grad_angles);
+  else
+    hipLaunchKernelGGL(qiddm::adjoint_finalize_kernel<double>, dim3(blocks), dim3(128), 0, st,
+                       static_cast<const double*>(k_partials), n_partials, n_rot, angles, grad_angles);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "adjoint_finalize launch failed: %s", hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
 int qiddm_dense_forward(const qiddm_circuit_t* c, const double* x, int64_t batch, int64_t x_ld,
                         int64_t in_features, const double* w_down, const double* b_down,
                         const double* angles, const double* w_up, const double* b_up,

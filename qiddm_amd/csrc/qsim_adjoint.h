@@ -401,4 +401,46 @@ __global__ __launch_bounds__(4 * kWave) void adjoint_kernel(const T* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------
+// finalize: sum the per-workgroup K slabs in a fixed order and contract with the analytic
+// dRot/d(phi, theta, omega):   dL/dangle = 2 Re sum_ab (dU/dangle)_ab K_ab      (float64)
+//   U00 =  e^{-ia} c   U01 = -e^{ib} s   U10 = e^{-ib} s   U11 = e^{ia} c,  a = (phi+omega)/2, b = (phi-omega)/2
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void adjoint_finalize_kernel(const T* __restrict__ k_partials, int64_t n_partials, int64_t n_rot,
+                                        const double* __restrict__ angles, double* __restrict__ grad_angles) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_rot) return;
+  double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t pidx = 0; pidx < n_partials; ++pidx) {
+    const T* src = k_partials + (pidx * n_rot + g) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] += (double)src[i];
+  }
+  const double phi = angles[g * 3 + 0], theta = angles[g * 3 + 1], omega = angles[g * 3 + 2];
+  double c, s, ca, sa, cb, sb;
+  sincos(0.5 * theta, &s, &c);
+  sincos(0.5 * (phi + omega), &sa, &ca);
+  sincos(0.5 * (phi - omega), &sb, &cb);
+  // Re(z * K) for z = (zr, zi), K = (kr, ki): zr*kr - zi*ki
+  auto re_mul = [](double zr, double zi, double kr, double ki) { return zr * kr - zi * ki; };
+  const double u00r = ca * c, u00i = -sa * c, u01r = -cb * s, u01i = -sb * s;
+  const double u10r = cb * s, u10i = -sb * s, u11r = ca * c, u11i = sa * c;
+  // multiply by -i/2: (x + iy)(-i/2) = (y - ix)/2 ; by +i/2: (-y + ix)/2
+  auto mi = [&](double xr, double xi, double kr, double ki) { return re_mul(0.5 * xi, -0.5 * xr, kr, ki); };
+  auto pi_ = [&](double xr, double xi, double kr, double ki) { return re_mul(-0.5 * xi, 0.5 * xr, kr, ki); };
+  const double d_phi = mi(u00r, u00i, k[0], k[1]) + pi_(u01r, u01i, k[2], k[3]) + mi(u10r, u10i, k[4], k[5]) +
+                       pi_(u11r, u11i, k[6], k[7]);
+  const double d_omega = mi(u00r, u00i, k[0], k[1]) + mi(u01r, u01i, k[2], k[3]) + pi_(u10r, u10i, k[4], k[5]) +
+                         pi_(u11r, u11i, k[6], k[7]);
+  // d/dtheta: c -> -s/2, s -> c/2
+  const double t00r = ca * (-0.5 * s), t00i = -sa * (-0.5 * s), t01r = -cb * (0.5 * c), t01i = -sb * (0.5 * c);
+  const double t10r = cb * (0.5 * c), t10i = -sb * (0.5 * c), t11r = ca * (-0.5 * s), t11i = sa * (-0.5 * s);
+  const double d_theta = re_mul(t00r, t00i, k[0], k[1]) + re_mul(t01r, t01i, k[2], k[3]) +
+                         re_mul(t10r, t10i, k[4], k[5]) + re_mul(t11r, t11i, k[6], k[7]);
+  grad_angles[g * 3 + 0] = 2.0 * d_phi;
+  grad_angles[g * 3 + 1] = 2.0 * d_theta;
+  grad_angles[g * 3 + 2] = 2.0 * d_omega;
+}
+
 }  // namespace qiddm
