@@ -214,6 +214,13 @@ def secondary_measurements(dev, batch):
                 opt.step()
             t = _time_fn(step, 10 if tag != "parameter_shift" else 2, warm=1)
             out[f"train_images_per_s_{tag}"] = xt.shape[0] * tau / t
+            if tag != "parameter_shift":
+                # the same step recorded once into a HIP graph (qiddm_amd.trainer), noise drawn on the device
+                from qiddm_amd.trainer import GraphedTrainStep
+                opt_g = torch.optim.Adam(diff.parameters(), lr=1e-3, capturable=True)
+                gstep = GraphedTrainStep(diff, opt_g, xt, T=tau, noise="device")
+                t = _time_fn(lambda: gstep(xt), 50, warm=3)
+                out[f"train_images_per_s_{tag}_graphed"] = xt.shape[0] * tau / t
         except Exception as e:  # pragma: no cover
             out[f"train_error_{tag}"] = repr(e)
     return out

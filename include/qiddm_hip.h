@@ -233,6 +233,44 @@ int qiddm_qconv_forward(const qiddm_circuit_t *circ, const double *x, int64_t ba
                         int64_t pad_h, int64_t pad_w, const double *angles, int64_t out_channels,
                         double *y, void *stream);
 
+/* ---- fused training step (device-resident Diffusion step) ---------------------------------
+ * Replaces, for nets of the linear_down -> circuit -> linear_up family (QNN_noise nn/qdense.py:267-289,
+ * QIDDM_LL_noise :1620-1642), one call of Diffusion.run_training_step_data / _noise
+ * (src/models.py:44-72 / :74-104) including its internal .backward(), with
+ * add_normal_noise_multiple (src/noise.py:105-126) as the noising schedule:
+ *     whole = x*(1-w_t) + noise*w_t, clamp      t = 0..tau        (never materialised)
+ *     noisy = whole[:, 1:], clean = whole[:, :-1]                 rows i = b*tau + (t-1)
+ *     out   = W_up <Z>(circuit(W_down noisy + b_down)) + b_up
+ *     goal 0 ("data"):  loss = mean((out - clean)^2)
+ *     goal 1 ("noise"): loss = mean(((out - 0.5)*0.1 - (noisy - clean))^2)
+ * Outputs: the scalar loss and d loss / d parameter for every parameter (overwritten, not accumulated).
+ * train_quantum = 0 reproduces the reference as written (SURVEY finding F1: the circuit output is
+ * detached, only linear_up receives a gradient; g_w_down/g_b_down/g_angles are not touched);
+ * train_quantum = 1 differentiates the circuit by the adjoint method (what diff_method="backprop"
+ * yields in the reference).  recon / elem_loss (optional, (batch*tau, pixels)) are what the verbose call
+ * returns: the reconstruction (goal 1: clamp(noisy - predicted, 0, 1)) and the element-wise loss.
+ * circ: QIDDM_MEAS_EXPZ, any angle encoding or none, n_qubits <= 10, any n_rounds.
+ * schedule: (tau+1) float32 weights with schedule[0] = 0; noise: float32 as the reference draws it.
+ * All sums have a fixed order: bit-reproducible.  Three launches on `stream`, no host synchronisation. */
+typedef struct qiddm_train_args {
+  const double *x;        /* (batch, pixels) float64, row stride x_ld                      */
+  const float *noise;     /* (batch, pixels) float32, row stride noise_ld                  */
+  const float *schedule;  /* (tau + 1)                                                     */
+  int64_t x_ld, noise_ld, batch;
+  int32_t pixels, tau, goal, train_quantum;
+  const double *w_down, *b_down;   /* (n, pixels), (n) or NULL                              */
+  const double *angles;            /* (n_rounds, n_blocks, sel_layers, n, 3)                */
+  const double *w_up, *b_up;       /* (pixels, n), (pixels) or NULL                         */
+  double *loss;                    /* (1)                                                   */
+  double *g_w_down, *g_b_down, *g_angles, *g_w_up, *g_b_up;
+  double *recon, *elem_loss;       /* optional                                              */
+} qiddm_train_args_t;
+
+/* bytes of scratch qiddm_train_step needs (negative: error code) */
+int64_t qiddm_train_workspace_bytes(const qiddm_circuit_t *circ, int64_t batch, int32_t pixels, int32_t tau);
+int qiddm_train_step(const qiddm_circuit_t *circ, const qiddm_train_args_t *args, void *workspace,
+                     int64_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,8 @@ EXPORTS = (
     "qiddm_dense_forward",
     "qiddm_dense_sample",
     "qiddm_qconv_forward",
+    "qiddm_train_workspace_bytes",
+    "qiddm_train_step",
 )
 
 
@@ -112,6 +114,27 @@ def _declare(lib):
     lib.qiddm_adjoint_finalize.argtypes = [P, vp, vp, i64, vp, vp]
     lib.qiddm_qconv_forward.restype = ctypes.c_int
     lib.qiddm_qconv_forward.argtypes = [P, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, vp, vp]
+    lib.qiddm_train_workspace_bytes.restype = ctypes.c_int64
+    lib.qiddm_train_workspace_bytes.argtypes = [P, i64, ctypes.c_int32, ctypes.c_int32]
+    lib.qiddm_train_step.restype = ctypes.c_int
+    lib.qiddm_train_step.argtypes = [P, ctypes.POINTER(TrainArgs), vp, i64, vp]
+
+
+class TrainArgs(ctypes.Structure):
+    """``qiddm_train_args_t``."""
+
+    _fields_ = [
+        ("x", ctypes.c_void_p), ("noise", ctypes.c_void_p), ("schedule", ctypes.c_void_p),
+        ("x_ld", ctypes.c_int64), ("noise_ld", ctypes.c_int64), ("batch", ctypes.c_int64),
+        ("pixels", ctypes.c_int32), ("tau", ctypes.c_int32), ("goal", ctypes.c_int32),
+        ("train_quantum", ctypes.c_int32),
+        ("w_down", ctypes.c_void_p), ("b_down", ctypes.c_void_p), ("angles", ctypes.c_void_p),
+        ("w_up", ctypes.c_void_p), ("b_up", ctypes.c_void_p),
+        ("loss", ctypes.c_void_p),
+        ("g_w_down", ctypes.c_void_p), ("g_b_down", ctypes.c_void_p), ("g_angles", ctypes.c_void_p),
+        ("g_w_up", ctypes.c_void_p), ("g_b_up", ctypes.c_void_p),
+        ("recon", ctypes.c_void_p), ("elem_loss", ctypes.c_void_p),
+    ]
 
 
 def _preload_torch_hip_runtime():

@@ -15,8 +15,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libqiddm_hip.so")
-SOURCES = ["qiddm_capi.hip"]
-HEADERS = ["qsim_fused.h", os.path.join("..", "..", "include", "qiddm_hip.h")]
+SOURCES = ["qiddm_capi.hip", "qiddm_train.hip"]
+OBJ_DIR = os.path.join(LIB_DIR, "obj")
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    return hs + [os.path.join(HERE, "..", "include", "qiddm_hip.h")]
 
 
 def _hipcc() -> str:
@@ -30,19 +36,32 @@ def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + _headers()
     return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    # one object per translation unit, compiled side by side, then one link
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print("[qiddm_amd.build]", " ".join(cmd), flush=True)
+        procs.append((cmd, obj, subprocess.Popen(cmd, cwd=CSRC)))
+    objs = []
+    for cmd, obj, proc in procs:
+        if proc.wait() != 0:
+            raise subprocess.CalledProcessError(proc.returncode, cmd)
+        objs.append(obj)
+    link = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs
     if verbose:
-        print("[qiddm_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True, cwd=CSRC)
+        print("[qiddm_amd.build]", " ".join(link), flush=True)
+    subprocess.run(link, check=True, cwd=CSRC)
     return LIB
 
 

@@ -257,6 +257,73 @@ def dense_sample(circ: Circuit, x: torch.Tensor, w_down, b_down, angles, w_up, b
     return y
 
 
+_train_workspaces = {}
+
+
+def train_step(circ: Circuit, x: torch.Tensor, noise: torch.Tensor, schedule: torch.Tensor, goal: str,
+               w_down, b_down, angles, w_up, b_up, train_quantum: bool, want_recon: bool = False,
+               want_elem_loss: bool = False, precision: str | None = None):
+    """One fused training step of the denoise loop (``qiddm_train_step``): noising, net forward, MSE and the
+    backward pass of ``Diffusion.run_training_step_data/_noise`` (reference src/models.py:44-104) for a
+    linear_down -> circuit -> linear_up net, in three launches and without a (batch*tau, pixels) tensor.
+
+    x (B, P) float64; noise (B, P) float32; schedule (tau+1,) float32 with schedule[0] == 0.
+    Returns a dict: ``loss`` (0-d), ``w_up``, ``b_up`` and -- when ``train_quantum`` -- ``w_down``, ``b_down``,
+    ``angles`` gradients (float64, parameter-shaped), plus ``recon`` / ``elem_loss`` (B*tau, P) on request."""
+    precision = precision or _default_precision
+    _require_device(angles, "the circuit weights")
+    _require_device(x, "the input batch")
+    device = angles.device
+    xx = _as_f64(x, device)
+    if xx.stride(1) != 1:
+        xx = xx.contiguous()
+    nz = noise.to(device=device, dtype=torch.float32)
+    if nz.stride(-1) != 1:
+        nz = nz.contiguous()
+    sch = schedule.to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+    wd, bd, wu, bu, ang = (_as_f64(t, device) for t in (w_down, b_down, w_up, b_up, angles))
+    if tuple(ang.shape) != circ.angles_shape:
+        raise ValueError(f"angles must have shape {circ.angles_shape}; got {tuple(ang.shape)}")
+    batch, pixels = xx.shape
+    tau = sch.numel() - 1
+    if tuple(nz.shape) != (batch, pixels):
+        raise ValueError(f"noise must have shape {(batch, pixels)}; got {tuple(nz.shape)}")
+    if tuple(wd.shape) != (circ.n_qubits, pixels) or tuple(wu.shape) != (pixels, circ.n_qubits):
+        raise ValueError("linear_down / linear_up must map pixels -> n_qubits -> pixels")
+    lib = _capi.lib()
+    cs = circ.c_struct(precision)
+    need = lib.qiddm_train_workspace_bytes(ctypes.byref(cs), batch, pixels, tau)
+    if need < 0:
+        _capi.check(int(need))
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _train_workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _train_workspaces[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    f64 = dict(dtype=torch.float64, device=device)
+    out = {"loss": torch.empty((), **f64), "w_up": torch.empty_like(wu), "b_up": torch.empty(pixels, **f64)}
+    if train_quantum:
+        out.update(w_down=torch.empty_like(wd), b_down=torch.empty(circ.n_qubits, **f64),
+                   angles=torch.empty_like(ang))
+    if want_recon:
+        out["recon"] = torch.empty(batch * tau, pixels, **f64)
+    if want_elem_loss:
+        out["elem_loss"] = torch.empty(batch * tau, pixels, **f64)
+
+    def ptr(t):
+        return 0 if t is None else t.data_ptr()
+
+    args = _capi.TrainArgs(
+        x=ptr(xx), noise=ptr(nz), schedule=ptr(sch), x_ld=xx.stride(0), noise_ld=nz.stride(0), batch=batch,
+        pixels=pixels, tau=tau, goal={"data": 0, "noise": 1}[goal], train_quantum=int(bool(train_quantum)),
+        w_down=ptr(wd), b_down=ptr(bd), angles=ptr(ang), w_up=ptr(wu), b_up=ptr(bu), loss=ptr(out["loss"]),
+        g_w_down=ptr(out.get("w_down")), g_b_down=ptr(out.get("b_down")), g_angles=ptr(out.get("angles")),
+        g_w_up=ptr(out["w_up"]), g_b_up=ptr(out["b_up"]), recon=ptr(out.get("recon")),
+        elem_loss=ptr(out.get("elem_loss")))
+    _capi.check(lib.qiddm_train_step(ctypes.byref(cs), ctypes.byref(args), ws.data_ptr(), ws.numel(),
+                                     _stream_ptr(device)))
+    return out
+
+
 def qconv_forward(x: torch.Tensor, angles: torch.Tensor, n_qubits: int, out_channels: int, kernel_size,
                   padding, precision: str | None = None) -> torch.Tensor:
     """The intended QConv2d forward in one launch (``qiddm_qconv_forward``); no autograd.

@@ -1,7 +1,7 @@
 // qiddm_capi.hip -- extern "C" entry points declared in include/qiddm_hip.h.
 // Argument validation, launch geometry and template dispatch only; the device
 // code lives in qsim_fused.h.
-#include "../../include/qiddm_hip.h"
+#include "capi_common.h"
 
 #include <hip/hip_runtime.h>
 
@@ -15,7 +15,7 @@
 #include "qsim_adjoint.h"
 #include "qsim_quad.h"
 
-namespace {
+namespace qiddm_capi {
 
 thread_local char g_err[512] = "";
 
@@ -62,6 +62,15 @@ int check_circuit(const qiddm_circuit_t* c) {
   return QIDDM_OK;
 }
 
+}  // namespace qiddm_capi
+
+namespace {
+
+using qiddm_capi::check_circuit;
+using qiddm_capi::fail;
+using qiddm_capi::g_err;
+using qiddm_capi::kMaxLds;
+
 struct Ptrs {
   const void* inputs = nullptr;
   const void* table = nullptr;
@@ -69,8 +78,6 @@ struct Ptrs {
   const void* gout = nullptr;
   void* dots = nullptr;
 };
-
-constexpr size_t kMaxLds = 160 * 1024;  // per-workgroup LDS on gfx950
 
 template <typename T, int N, bool SHIFT>
 int launch(const Ptrs& ptr, const qiddm::KScalars& p, int64_t n_replicas, hipStream_t stream) {
@@ -654,13 +661,13 @@ int qiddm_adjoint_finalize(const qiddm_circuit_t* c, const double* angles, const
   if (!angles || !k_partials || !grad_angles) return fail(QIDDM_ERR_INVALID, "angles/k_partials/grad_angles is NULL");
   if (n_partials < 0) return fail(QIDDM_ERR_INVALID, "n_partials < 0");
   const int64_t n_rot = (int64_t)c->n_rounds * c->n_blocks * c->sel_layers * c->n_qubits;
-  const unsigned blocks = (unsigned)((n_rot + 127) / 128);
+  const unsigned blocks = (unsigned)n_rot;  // one wavefront per gate
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (c->dtype == QIDDM_F32)
-    hipLaunchKernelGGL(qiddm::adjoint_finalize_kernel<float>, dim3(blocks), dim3(128), 0, st,
+    hipLaunchKernelGGL(qiddm::adjoint_finalize_kernel<float>, dim3(blocks), dim3(qiddm::kWave), 0, st,
                        static_cast<const float*>(k_partials), n_partials, n_rot, angles, grad_angles);
   else
-    hipLaunchKernelGGL(qiddm::adjoint_finalize_kernel<double>, dim3(blocks), dim3(128), 0, st,
+    hipLaunchKernelGGL(qiddm::adjoint_finalize_kernel<double>, dim3(blocks), dim3(qiddm::kWave), 0, st,
                        static_cast<const double*>(k_partials), n_partials, n_rot, angles, grad_angles);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "adjoint_finalize launch failed: %s", hipGetErrorString(e));

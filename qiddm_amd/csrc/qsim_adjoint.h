@@ -193,18 +193,14 @@ struct AdjointEngine {
     }
   }
 
-  // ---- one sample (group): forward, then the reverse sweep ------------------------------------------
-  // g_row: upstream gradient row ((2^N) probabilities or N expectation values).
-  // gin_row: where this sample's input gradient goes (may be null).
+  // ---- one round, forward: |0..0> or the embedded row -> psi_final.  Leaves what the reverse sweep needs
+  // (half-angle sin/cos, the RZ diagonal, 1/|v| of the embedding) in the caller's registers.
   template <typename Src>
-  __device__ __forceinline__ void run(const KScalars& p, const Src& amp_src, T (&xs)[N],
-                                      const T* __restrict__ g_row, T* __restrict__ gin_row, bool valid) const {
+  __device__ __forceinline__ void forward_round(const KScalars& p, const Src& amp_src, const T (&xs)[N], C (&psi)[R],
+                                                C (&dx)[R], T (&cs)[N], T (&sn)[N], T& amp_inv) const {
     const bool use_cnot = p.imprimitive == 0;
-    const int lane = fwd.lane, llane = fwd.llane, sub = fwd.sub;
-    C psi[R], dx[R];
-    T cs[N], sn[N];
-    T amp_inv = 1;
-    // ---- forward (one round) ---------------------------------------------------------------------
+    const int lane = fwd.lane, sub = fwd.sub;
+    amp_inv = 1;
     if (p.encoding == 1) {
       T n2 = 0;
 #pragma unroll
@@ -226,47 +222,57 @@ struct AdjointEngine {
     }
     if (p.encoding >= 2) fwd.half_angle_sincos(xs, cs, sn);
     if (p.encoding == 2) fwd.rz_diagonal(cs, sn, dx);
-    {
-      C gate_m[8];
-      fwd.template load_gate<0>(0, gate_m);
-      const int n_rot = p.n_blocks * p.sel_layers * N;
-      for (int blk = 0; blk < p.n_blocks; ++blk) {
-        if (p.encoding == 2) {
+    C gate_m[8];
+    fwd.template load_gate<0>(0, gate_m);
+    const int n_rot = p.n_blocks * p.sel_layers * N;
+    for (int blk = 0; blk < p.n_blocks; ++blk) {
+      if (p.encoding == 2) {
 #pragma unroll
-          for (int r = 0; r < R; ++r) psi[r] = cmul2<T>(dx[r], psi[r], times_i<T>(psi[r]));
-        } else if ((p.encoding == 3 && blk == 0) || p.encoding == 4) {
-          fwd.template ry_layer<0>(psi, cs, sn);
-        }
-        for (int s = 0; s < p.sel_layers; ++s) {
-          const int gate0 = (blk * p.sel_layers + s) * N;
-          fwd.rot_layer(psi, gate0, gate0 + N < n_rot ? gate0 + N : 0, gate_m);
-          if constexpr (N > 1) fwd.ring(psi, s % (N - 1), use_cnot);
-        }
+        for (int r = 0; r < R; ++r) psi[r] = cmul2<T>(dx[r], psi[r], times_i<T>(psi[r]));
+      } else if ((p.encoding == 3 && blk == 0) || p.encoding == 4) {
+        fwd.template ry_layer<0>(psi, cs, sn);
+      }
+      for (int s = 0; s < p.sel_layers; ++s) {
+        const int gate0 = (blk * p.sel_layers + s) * N;
+        fwd.rot_layer(psi, gate0, gate0 + N < n_rot ? gate0 + N : 0, gate_m);
+        if constexpr (N > 1) fwd.ring(psi, s % (N - 1), use_cnot);
       }
     }
-    // ---- lambda = diag(g_eff) psi_final ----------------------------------------------------------------
-    C lam[R];
-    if (p.measure == 0) {
+  }
+
+  // <Z_w> of every wire, broadcast to all lanes of the sample
+  __device__ __forceinline__ void measure_expz(const C (&psi)[R], T (&result)[N]) const {
+    T pr[R];
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const T g = valid ? g_row[(r << LB) | sub] : (T)0;
-        lam[r] = C{g * psi[r].x, g * psi[r].y};
-      }
-    } else {
-      T gw[N];
+    for (int r = 0; r < R; ++r) pr[r] = psi[r].x * psi[r].x + psi[r].y * psi[r].y;
 #pragma unroll
-      for (int w = 0; w < N; ++w) gw[w] = valid ? g_row[w] : (T)0;
+    for (int w = 0; w < N; ++w) {
+      const int q = N - 1 - w;
+      T acc = 0;
 #pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const int k = (r << LB) | sub;
-        T g = 0;
-#pragma unroll
-        for (int w = 0; w < N; ++w) g += ((k >> (N - 1 - w)) & 1) ? -gw[w] : gw[w];
-        lam[r] = C{g * psi[r].x, g * psi[r].y};
-      }
+      for (int r = 0; r < R; ++r) acc += ((((r << LB) | fwd.sub) >> q) & 1) ? -pr[r] : pr[r];
+      result[w] = group_sum<T, LB>(acc, fwd.lane);
     }
-    // ---- reverse sweep ----------------------------------------------------------------------------------------
-    T gx[N];
+  }
+
+  // lambda = diag(sum_w g_w z_w(k)) psi   (upstream gradient on the <Z_w> read-out)
+  __device__ __forceinline__ void seed_expz(const T (&gw)[N], const C (&psi)[R], C (&lam)[R]) const {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int k = (r << LB) | fwd.sub;
+      T g = 0;
+#pragma unroll
+      for (int w = 0; w < N; ++w) g += ((k >> (N - 1 - w)) & 1) ? -gw[w] : gw[w];
+      lam[r] = C{g * psi[r].x, g * psi[r].y};
+    }
+  }
+
+  // ---- one round, backwards: un-applies every gate to psi and lambda, banks K of the Rot gates in kacc and
+  // the per-lane partial input gradients in gx (angle encodings)
+  __device__ __forceinline__ void reverse_round(const KScalars& p, C (&psi)[R], C (&lam)[R], const C (&dx)[R],
+                                                const T (&cs)[N], const T (&sn)[N], T (&gx)[N]) const {
+    const bool use_cnot = p.imprimitive == 0;
+    const int llane = fwd.llane;
 #pragma unroll
     for (int w = 0; w < N; ++w) gx[w] = 0;
     for (int blk = p.n_blocks - 1; blk >= 0; --blk) {
@@ -306,6 +312,35 @@ struct AdjointEngine {
         ry_steps_back<0>(psi, lam, cs, sn, gx);
       }
     }
+  }
+
+  // ---- one sample (group): forward, then the reverse sweep ------------------------------------------
+  // g_row: upstream gradient row ((2^N) probabilities or N expectation values).
+  // gin_row: where this sample's input gradient goes (may be null).
+  template <typename Src>
+  __device__ __forceinline__ void run(const KScalars& p, const Src& amp_src, T (&xs)[N],
+                                      const T* __restrict__ g_row, T* __restrict__ gin_row, bool valid) const {
+    const int lane = fwd.lane, sub = fwd.sub;
+    C psi[R], dx[R];
+    T cs[N], sn[N];
+    T amp_inv;
+    forward_round(p, amp_src, xs, psi, dx, cs, sn, amp_inv);
+    // ---- lambda = diag(g_eff) psi_final ----------------------------------------------------------------
+    C lam[R];
+    if (p.measure == 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const T g = valid ? g_row[(r << LB) | sub] : (T)0;
+        lam[r] = C{g * psi[r].x, g * psi[r].y};
+      }
+    } else {
+      T gw[N];
+#pragma unroll
+      for (int w = 0; w < N; ++w) gw[w] = valid ? g_row[w] : (T)0;
+      seed_expz(gw, psi, lam);
+    }
+    T gx[N];
+    reverse_round(p, psi, lam, dx, cs, sn, gx);
     // ---- input gradients -----------------------------------------------------------------------------------------
     if (gin_row != nullptr) {
       if (p.encoding >= 2) {
@@ -401,23 +436,10 @@ __global__ __launch_bounds__(4 * kWave) void adjoint_kernel(const T* __restrict_
   }
 }
 
-// ---------------------------------------------------------------------------
-// finalize: sum the per-workgroup K slabs in a fixed order and contract with the analytic
-// dRot/d(phi, theta, omega):   dL/dangle = 2 Re sum_ab (dU/dangle)_ab K_ab      (float64)
+// 2 Re sum_ab (dU/dangle)_ab K_ab for the three angles of one Rot gate (float64); k = K00 K01 K10 K11 as (re, im)
 //   U00 =  e^{-ia} c   U01 = -e^{ib} s   U10 = e^{-ib} s   U11 = e^{ia} c,  a = (phi+omega)/2, b = (phi-omega)/2
-// ---------------------------------------------------------------------------
-template <typename T>
-__global__ void adjoint_finalize_kernel(const T* __restrict__ k_partials, int64_t n_partials, int64_t n_rot,
-                                        const double* __restrict__ angles, double* __restrict__ grad_angles) {
-  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= n_rot) return;
-  double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int64_t pidx = 0; pidx < n_partials; ++pidx) {
-    const T* src = k_partials + (pidx * n_rot + g) * 8;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) k[i] += (double)src[i];
-  }
-  const double phi = angles[g * 3 + 0], theta = angles[g * 3 + 1], omega = angles[g * 3 + 2];
+__device__ __forceinline__ void rot_grad_from_k(const double (&k)[8], double phi, double theta, double omega,
+                                                double* __restrict__ out3) {
   double c, s, ca, sa, cb, sb;
   sincos(0.5 * theta, &s, &c);
   sincos(0.5 * (phi + omega), &sa, &ca);
@@ -438,9 +460,35 @@ __global__ void adjoint_finalize_kernel(const T* __restrict__ k_partials, int64_
   const double t10r = cb * (0.5 * c), t10i = -sb * (0.5 * c), t11r = ca * (-0.5 * s), t11i = sa * (-0.5 * s);
   const double d_theta = re_mul(t00r, t00i, k[0], k[1]) + re_mul(t01r, t01i, k[2], k[3]) +
                          re_mul(t10r, t10i, k[4], k[5]) + re_mul(t11r, t11i, k[6], k[7]);
-  grad_angles[g * 3 + 0] = 2.0 * d_phi;
-  grad_angles[g * 3 + 1] = 2.0 * d_theta;
-  grad_angles[g * 3 + 2] = 2.0 * d_omega;
+  out3[0] = 2.0 * d_phi;
+  out3[1] = 2.0 * d_theta;
+  out3[2] = 2.0 * d_omega;
+}
+
+// ---------------------------------------------------------------------------
+// finalize: sum the per-workgroup K slabs in a fixed order and contract with the analytic
+// dRot/d(phi, theta, omega):   dL/dangle = 2 Re sum_ab (dU/dangle)_ab K_ab      (float64)
+//   U00 =  e^{-ia} c   U01 = -e^{ib} s   U10 = e^{-ib} s   U11 = e^{ia} c,  a = (phi+omega)/2, b = (phi-omega)/2
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kWave) void adjoint_finalize_kernel(const T* __restrict__ k_partials,
+                                                                 int64_t n_partials, int64_t n_rot,
+                                                                 const double* __restrict__ angles,
+                                                                 double* __restrict__ grad_angles) {
+  // one wavefront per gate: lanes stride over the workgroup slabs, then a fixed-order butterfly
+  const int64_t g = blockIdx.x;
+  if (g >= n_rot) return;
+  const int lane = threadIdx.x;
+  double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t pidx = lane; pidx < n_partials; pidx += kWave) {
+    const T* src = k_partials + (pidx * n_rot + g) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] += (double)src[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k[i] = group_sum<double, 6>(k[i], lane);
+  if (lane != 0) return;
+  rot_grad_from_k(k, angles[g * 3 + 0], angles[g * 3 + 1], angles[g * 3 + 2], grad_angles + g * 3);
 }
 
 }  // namespace qiddm

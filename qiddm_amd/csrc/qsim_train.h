@@ -1,0 +1,382 @@
+// qsim_train.h -- the training step of the denoise loop on the device.
+//
+// Reference: Diffusion.run_training_step_data / _noise (src/models.py:44-104) around a net of the
+// linear_down -> circuit -> linear_up family (QNN_noise nn/qdense.py:267-289, QIDDM_LL_noise :1620-1642) with
+// add_normal_noise_multiple (src/noise.py:105-126) as the forward-noising schedule:
+//
+//     whole  = noise_f(x, T+1, decay 3)                  (B, T+1, P)
+//     noisy  = whole[:, 1:], clean = whole[:, :-1]       (B*T, P) rows i = b*T + t-1
+//     out    = W_up <Z>(circuit(W_down noisy + b_down)) + b_up
+//     loss   = mean((out - clean)^2)                                   goal "data"
+//            = mean(((out - 0.5) * 0.1 - (noisy - clean))^2)           goal "noise"
+//     loss.backward()
+//
+// Nothing of size (B*T, P) is materialised: the noisy / clean rows are re-derived from x (B, P) and the one
+// noise field (B, P) wherever they are needed.  Four launches:
+//   1a. train_project_kernel one wavefront per (sample, noise level): the blended row's dot products with the
+//                            columns of W_down and W_up -- the only place the circuit stage touches pixels.
+//   1b. train_rows_kernel    one wavefront per row: circuit forward (all rounds) -> d loss / d <Z> from the
+//                            projections -> adjoint sweep -> d loss / d (W_down x).  Writes <Z> (rows, n), the
+//                            input gradient (rows, n), per-workgroup K slabs.  No pixel loop, no weights in LDS.
+//   2. train_weight_grads_kernel   the four weight/bias gradients are sums over rows of rank-1 terms; a thread
+//                            owns one pixel column, walks a chunk of samples, recomputes out / residual / noisy in
+//                            float64 and keeps 2n+1 accumulators.  Also the loss (and, on request, the
+//                            reconstruction and the element-wise loss the verbose call returns).
+//   3. train_finalize_kernel fixed-order sums of the chunk partials, the loss, b_down's gradient, and the
+//                            contraction of K with dRot/d(phi, theta, omega).
+// All reductions have a fixed order: the step is bit-reproducible run to run.
+#pragma once
+#include "qsim_adjoint.h"
+
+namespace qiddm {
+
+struct TrainScalars {
+  int64_t x_ld, noise_ld, rows;  // rows = B * T
+  int32_t pixels, T, goal, train_quantum;
+  int32_t samples_per_chunk, n_chunks, want_recon, want_elem;
+  double grad_scale;  // d(mean loss) / d(out) = grad_scale * residual
+};
+
+// x * (1 - w) + noise * w, clamped -- in torch's order of roundings for a float64 x and float32 noise / w
+// (src/noise.py:118-124): (1 - w) and noise * w are float32 results, the rest is float64, no contraction.
+__device__ __forceinline__ double blend_noise(double xv, float nz, float w) {
+  const float omw = __fsub_rn(1.0f, w);
+  const float nw = __fmul_rn(nz, w);
+  const double v = __dadd_rn(__dmul_rn(xv, (double)omw), (double)nw);
+  return fmin(fmax(v, 0.0), 1.0);
+}
+
+__device__ __forceinline__ double residual(int goal, double out, double noisy, double clean) {
+  return goal == 0 ? out - clean : (out - 0.5) * 0.1 - (noisy - clean);
+}
+
+// ---------------------------------------------------------------------------
+// 1a. projections.  Every place the (rows, P) tensors meet a weight matrix is a dot product of a blended row
+// with a column of W_down or W_up, so they are all taken here, once, one wavefront per (sample b, level t):
+//     proj[(b*(T+1)+t)*2n + j]     = sum_p whole[b,t,p] W_down[j,p]            j < n
+//     proj[(b*(T+1)+t)*2n + n + j] = sum_p whole[b,t,p] W_up[p,j]
+// and n+2 more units with W_up[:,j'], b_up and 1 in place of `whole` (G = W_up^T W_up, c = W_up^T b_up,
+// s = W_up^T 1) at unit index B*(T+1) + {0..n-1, n, n+1}.  With these the circuit kernel needs no pixel loop:
+//     d loss / d <Z_j> = grad_scale * ((G ev + c)_j - CU_j)                                  goal "data"
+//                      = grad_scale * (0.1 (G ev + c)_j - 0.05 s_j - NU_j + CU_j)            goal "noise"
+// (NU / CU = the W_up projections of the noisy / clean row).
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(4 * kWave) void train_project_kernel(
+    const double* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ sched,
+    const double* __restrict__ wd, const double* __restrict__ wu, const double* __restrict__ bu,
+    double* __restrict__ proj, int64_t batch, const TrainScalars d) {
+  const int P = d.pixels;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int64_t unit = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t n_blend = batch * (d.T + 1);
+  if (unit >= n_blend + N + 2) return;
+  const int kind = unit < n_blend ? 0 : (int)(unit - n_blend) + 1;  // 0 blend, 1..N W_up column, N+1 b_up, N+2 ones
+  const int64_t b = kind == 0 ? unit / (d.T + 1) : 0;
+  const int t = kind == 0 ? (int)(unit - b * (d.T + 1)) : 0;
+  const float w = sched[t];
+  double acc[2 * N];
+#pragma unroll
+  for (int j = 0; j < 2 * N; ++j) acc[j] = 0.0;
+  constexpr int U = 8;
+  for (int p0 = lane; p0 < P; p0 += kWave * U) {
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int pix = p0 + u * kWave;
+      const int pc = pix < P ? pix : 0;
+      double val;
+      if (kind == 0) val = blend_noise(x[b * d.x_ld + pc], noise[b * d.noise_ld + pc], w);
+      else if (kind <= N) val = wu[(size_t)pc * N + (kind - 1)];
+      else if (kind == N + 1) val = bu ? bu[pc] : 0.0;
+      else val = 1.0;
+      v[u] = pix < P ? val : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int pix = p0 + u * kWave;
+      const int pc = pix < P ? pix : 0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        if (kind == 0) acc[j] = fma(v[u], wd[(size_t)j * P + pc], acc[j]);
+        acc[N + j] = fma(v[u], wu[(size_t)pc * N + j], acc[N + j]);
+      }
+    }
+  }
+  double mine = 0.0;
+#pragma unroll
+  for (int j = 0; j < 2 * N; ++j) {
+    const double tot = group_sum<double, 6>(acc[j], lane);
+    mine = fma((double)(lane == j ? 1 : 0), tot, mine);
+  }
+  if (lane < 2 * N) proj[unit * (2 * N) + lane] = mine;
+}
+
+template <typename T, int N>
+__host__ __device__ inline size_t train_lds_bytes(int64_t n_rot_all, int n_rounds, bool cnot, int waves,
+                                                  bool quantum) {
+  size_t b = Smem<T, N>::bytes(n_rot_all, cnot, waves);
+  if (quantum) b += (size_t)n_rot_all * kLdsGateReals * sizeof(T) + (size_t)waves * n_rot_all * 8 * sizeof(T);
+  b += (size_t)waves * Layout<N>::SPW * n_rounds * N * sizeof(T);
+  return b;
+}
+
+// ---------------------------------------------------------------------------
+// 1b. the circuit, forward and (QUANTUM) reverse, one wavefront per row
+// ---------------------------------------------------------------------------
+template <typename T, int N, bool QUANTUM, int WPB>
+__global__ __launch_bounds__(WPB* kWave, 2) void train_rows_kernel(
+    const double* __restrict__ proj, const double* __restrict__ bd, const double* __restrict__ angles,
+    double* __restrict__ ev_out, double* __restrict__ gxr_out, T* __restrict__ k_partials, int64_t batch,
+    const TrainScalars d, const KScalars p) {
+  using E = Engine<T, N>;
+  using L = typename E::L;
+  using C = V2<T>;
+  constexpr int LB = L::LB, R = L::R, SPW = L::SPW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int n_rot = p.n_blocks * p.sel_layers * N;  // per round
+  const int n_rot_all = p.n_rounds * n_rot;
+  const bool use_cnot = p.imprimitive == 0;
+
+  AdjointEngine<T, N> adj;
+  adj.fwd.carve(smem_raw, n_rot_all);
+  unsigned char* cur = smem_raw + Smem<T, N>::bytes(n_rot_all, use_cnot, WPB);
+  T* dag_gates = reinterpret_cast<T*>(cur);
+  T* kall = dag_gates;
+  if constexpr (QUANTUM) {
+    kall = dag_gates + (size_t)n_rot_all * kLdsGateReals;
+    cur = reinterpret_cast<unsigned char*>(kall + (size_t)WPB * n_rot_all * 8);
+  }
+  T* hist_all = reinterpret_cast<T*>(cur);
+  adj.fwd.fill_gates_from_angles(angles, n_rot_all);
+  adj.fwd.fill_rings(use_cnot);
+  if constexpr (QUANTUM)
+    for (int i = threadIdx.x; i < WPB * n_rot_all * 8; i += blockDim.x) kall[i] = 0;
+  __syncthreads();
+  if constexpr (QUANTUM) {
+    // U^dagger images from the forward ones: (u00*, u10*; u01*, u11*)
+    for (int g = threadIdx.x; g < n_rot_all; g += blockDim.x) {
+      const T* f = adj.fwd.s_gates_w + (size_t)g * kLdsGateReals;
+      E::put_gate(dag_gates + (size_t)g * kLdsGateReals, f[0], -f[1], f[12], -f[13], f[4], -f[5], f[8], -f[9]);
+    }
+    __syncthreads();
+  }
+  adj.dag = adj.fwd;
+  const T* fwd_base = adj.fwd.s_gates;
+  const int lane = adj.fwd.lane, sub = adj.fwd.sub;
+  const int wave = threadIdx.x >> 6;
+  const int swave = adj.fwd.llane >> LB;
+  T* kacc_wave = kall + (size_t)wave * n_rot_all * 8;
+  T* hist = hist_all + (size_t)(wave * SPW + swave) * p.n_rounds * N;
+  const double* __restrict__ gram = proj + batch * (d.T + 1) * (2 * N) + N;  // row j' of G at gram[j'*2N + j]
+  const double* __restrict__ cvec = gram + (size_t)N * (2 * N);
+  const double* __restrict__ svec = cvec + 2 * N;
+
+  const int64_t groups = (d.rows + SPW - 1) / SPW;
+  for (int64_t grp = (int64_t)blockIdx.x * WPB + wave; grp < groups; grp += (int64_t)gridDim.x * WPB) {
+    const int64_t row_raw = grp * SPW + swave;
+    const bool valid = row_raw < d.rows;
+    const int64_t row = valid ? row_raw : d.rows - 1;
+    const int64_t b = row / d.T;
+    const int t = (int)(row - b * d.T) + 1;
+    const double* __restrict__ pn = proj + (b * (d.T + 1) + t) * (2 * N);  // noisy row's projections
+    const double* __restrict__ pcl = pn - 2 * N;                           // clean row's (level t-1)
+    T xs[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) xs[j] = (T)((pn[j] + (bd ? bd[j] : 0.0)) * p.enc_scale);
+
+    // ---- the circuit, all rounds; the last round's state stays in registers for the reverse sweep ----
+    C psi[R], dx[R];
+    T cs[N], sn[N], amp_inv;
+    T result[N];
+    for (int round = 0; round < p.n_rounds; ++round) {
+      if (QUANTUM && sub == 0) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) hist[round * N + j] = xs[j];
+      }
+      adj.fwd.s_gates = fwd_base + (size_t)round * n_rot * kLdsGateReals;
+      adj.forward_round(p, NoSrc{}, xs, psi, dx, cs, sn, amp_inv);
+      adj.measure_expz(psi, result);
+      if (round + 1 < p.n_rounds) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) xs[j] = result[j] * (T)p.enc_scale;
+      }
+    }
+    {
+      double v = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) v = fma((double)(sub == j ? 1 : 0), (double)result[j], v);
+      if (valid && sub < N) ev_out[row * N + sub] = v;
+    }
+    if constexpr (QUANTUM) {
+      // ---- d loss / d <Z_j> from the projections ---------------------------------------------------
+      T gw[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        double ge = cvec[j];
+#pragma unroll
+        for (int jp = 0; jp < N; ++jp) ge = fma(gram[(size_t)jp * (2 * N) + j], (double)result[jp], ge);
+        const double g = d.goal == 0 ? ge - pcl[N + j] : 0.1 * ge - 0.05 * svec[j] - pn[N + j] + pcl[N + j];
+        gw[j] = valid ? (T)(d.grad_scale * g) : (T)0;
+      }
+      // ---- reverse sweep, last round first; earlier rounds are re-run forward from their recorded inputs ----
+      for (int round = p.n_rounds - 1; round >= 0; --round) {
+        adj.fwd.s_gates = fwd_base + (size_t)round * n_rot * kLdsGateReals;
+        adj.dag.s_gates = dag_gates + (size_t)round * n_rot * kLdsGateReals;
+        adj.kacc = kacc_wave + (size_t)round * n_rot * 8;
+        if (round != p.n_rounds - 1) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) xs[j] = hist[round * N + j];
+          adj.forward_round(p, NoSrc{}, xs, psi, dx, cs, sn, amp_inv);
+        }
+        C lam[R];
+        adj.seed_expz(gw, psi, lam);
+        T gx[N];
+        adj.reverse_round(p, psi, lam, dx, cs, sn, gx);
+#pragma unroll
+        for (int j = 0; j < N; ++j) gw[j] = group_sum<T, LB>(gx[j], lane) * (T)p.enc_scale;
+      }
+      double v = 0.0;
+#pragma unroll
+      for (int j = 0; j < N; ++j) v = fma((double)(sub == j ? 1 : 0), (double)gw[j], v);
+      if (valid && sub < N) gxr_out[row * N + sub] = v;
+    }
+  }
+  if constexpr (QUANTUM) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_rot_all * 8; i += blockDim.x) {
+      T tot = 0;
+      for (int w = 0; w < WPB; ++w) tot += kall[(size_t)w * n_rot_all * 8 + i];
+      k_partials[(size_t)blockIdx.x * n_rot_all * 8 + i] = tot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// weight / bias gradient partials, loss partials, optional verbose outputs.  grid (pixel tiles, chunks), 64 threads.
+// partials layout [chunk][2n+1][P]: rows 0..n-1 dW_up[:, j], row n db_up, rows n+1.. dW_down[j, :]
+// ---------------------------------------------------------------------------
+template <int N>
+__global__ __launch_bounds__(kWave) void train_weight_grads_kernel(
+    const double* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ sched,
+    const double* __restrict__ wu, const double* __restrict__ bu, const double* __restrict__ ev,
+    const double* __restrict__ gxr, double* __restrict__ partials, double* __restrict__ loss_partials,
+    double* __restrict__ recon, double* __restrict__ elem, int64_t batch, const TrainScalars d) {
+  const int P = d.pixels;
+  const int pix = blockIdx.x * kWave + threadIdx.x;
+  const bool pvalid = pix < P;
+  const int pc = pvalid ? pix : 0;
+  const int chunk = blockIdx.y;
+  const int64_t b0 = (int64_t)chunk * d.samples_per_chunk;
+  const int64_t b1 = b0 + d.samples_per_chunk < batch ? b0 + d.samples_per_chunk : batch;
+  const bool quantum = d.train_quantum != 0;
+  double wur[N], acc_wu[N], acc_wd[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j) {
+    wur[j] = wu[(size_t)pc * N + j];
+    acc_wu[j] = 0.0;
+    acc_wd[j] = 0.0;
+  }
+  const double buv = bu ? bu[pc] : 0.0;
+  double acc_bu = 0.0, loss = 0.0;
+  for (int64_t b = b0; b < b1; ++b) {
+    const double xv = x[b * d.x_ld + pc];
+    const float nz = noise[b * d.noise_ld + pc];
+    double clean = blend_noise(xv, nz, sched[0]);
+    for (int t = 1; t <= d.T; ++t) {
+      const double noisy = blend_noise(xv, nz, sched[t]);
+      const int64_t row = b * d.T + (t - 1);
+      const double* __restrict__ evp = ev + row * N;
+      double o = buv;
+#pragma unroll
+      for (int j = 0; j < N; ++j) o = fma(evp[j], wur[j], o);
+      const double r = residual(d.goal, o, noisy, clean);
+      const double g = d.grad_scale * r;
+      loss = fma(r, r, loss);
+      acc_bu += g;
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc_wu[j] = fma(g, evp[j], acc_wu[j]);
+      if (quantum) {
+        const double* __restrict__ gp = gxr + row * N;
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc_wd[j] = fma(gp[j], noisy, acc_wd[j]);
+      }
+      if (pvalid) {
+        if (d.want_recon)
+          recon[row * P + pix] = d.goal == 0 ? o : fmin(fmax(noisy - (o - 0.5) * 0.1, 0.0), 1.0);
+        if (d.want_elem) elem[row * P + pix] = r * r;
+      }
+      clean = noisy;
+    }
+  }
+  if (pvalid) {
+    double* dst = partials + (size_t)chunk * (2 * N + 1) * P + pix;
+#pragma unroll
+    for (int j = 0; j < N; ++j) dst[(size_t)j * P] = acc_wu[j];
+    dst[(size_t)N * P] = acc_bu;
+    if (quantum) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) dst[(size_t)(N + 1 + j) * P] = acc_wd[j];
+    }
+  }
+  loss = group_sum<double, 6>(pvalid ? loss : 0.0, threadIdx.x);
+  if (threadIdx.x == 0) loss_partials[(size_t)chunk * gridDim.x + blockIdx.x] = loss;
+}
+
+// roles by workgroup: [0, wblocks) weight sums; wblocks: loss; n x db_down[j]; then one wavefront per Rot gate
+template <typename T>
+__global__ __launch_bounds__(kWave) void train_finalize_kernel(
+    const double* __restrict__ partials, const double* __restrict__ loss_partials, int64_t n_loss_partials,
+    const double* __restrict__ gxr, const T* __restrict__ k_partials, int64_t n_k_partials,
+    const double* __restrict__ angles, int n, int64_t n_rot_all, int wblocks, double* __restrict__ loss,
+    double* __restrict__ g_wd, double* __restrict__ g_bd, double* __restrict__ g_angles,
+    double* __restrict__ g_wu, double* __restrict__ g_bu, const TrainScalars d) {
+  const int P = d.pixels;
+  const int lane = threadIdx.x;
+  const int role = blockIdx.x;
+  if (role < wblocks) {
+    const int rows = d.train_quantum ? 2 * n + 1 : n + 1;
+    const int64_t idx = (int64_t)role * kWave + lane;
+    if (idx >= (int64_t)rows * P) return;
+    const int k = (int)(idx / P), pix = (int)(idx - (int64_t)k * P);
+    double tot = 0.0;
+#pragma unroll 8
+    for (int c = 0; c < d.n_chunks; ++c) tot += partials[((size_t)c * (2 * n + 1) + k) * P + pix];
+    if (k < n) g_wu[(size_t)pix * n + k] = tot;
+    else if (k == n) g_bu[pix] = tot;
+    else g_wd[(size_t)(k - n - 1) * P + pix] = tot;
+    return;
+  }
+  if (role == wblocks) {
+    double tot = 0.0;
+#pragma unroll 8
+    for (int64_t i = lane; i < n_loss_partials; i += kWave) tot += loss_partials[i];
+    tot = group_sum<double, 6>(tot, lane);
+    if (lane == 0) loss[0] = tot / ((double)d.rows * (double)P);
+    return;
+  }
+  if (role <= wblocks + n) {  // db_down[j]: one wavefront per j
+    if (!d.train_quantum) return;
+    const int j = role - wblocks - 1;
+    double sum = 0.0;
+#pragma unroll 8
+    for (int64_t r = lane; r < d.rows; r += kWave) sum += gxr[r * n + j];
+    sum = group_sum<double, 6>(sum, lane);
+    if (lane == 0) g_bd[j] = sum;
+    return;
+  }
+  const int64_t g = role - wblocks - 1 - n;
+  if (g >= n_rot_all) return;
+  double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 4
+  for (int64_t pidx = lane; pidx < n_k_partials; pidx += kWave) {
+    const T* src = k_partials + (pidx * n_rot_all + g) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) k[i] += (double)src[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k[i] = group_sum<double, 6>(k[i], lane);
+  if (lane == 0) rot_grad_from_k(k, angles[g * 3 + 0], angles[g * 3 + 1], angles[g * 3 + 2], g_angles + g * 3);
+}
+
+}  // namespace qiddm

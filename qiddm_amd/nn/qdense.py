@@ -73,6 +73,39 @@ class _QuantumNet(nn.Module):
         return (not torch.is_grad_enabled()) and self.qnode is self._own_qnode and \
             getattr(self, "add_noise", 0) in self._fusable_noise
 
+    # -- fused training step -------------------------------------------------
+    def _train_family(self):
+        """``(circuit, linear_down, angles parameter, linear_up)`` for nets of the
+        linear_down -> angle-encoded circuit -> <Z> -> linear_up shape; None otherwise."""
+        return None
+
+    def fused_train_step(self, x, noise, schedule, goal, want_recon=False, want_elem_loss=False):
+        """What ``Diffusion.run_training_step_*`` does around this net -- noising, forward, MSE, backward --
+        in three launches (``qiddm_train_step``).  Adds the gradients to ``.grad`` exactly where ``.backward()``
+        would (with ``detach_quantum`` only ``linear_up`` receives one, finding F1) and returns the dict of
+        ``circuit.train_step`` (``loss``, optional ``recon`` / ``elem_loss``); None when the net or its
+        current settings are outside the fused step (the caller then runs the eager path)."""
+        fam = self._train_family()
+        if fam is None or self.qnode is not self._own_qnode or \
+                getattr(self, "add_noise", 0) not in self._fusable_noise:
+            return None
+        circ, lin_down, angles, lin_up = fam
+        if circ.n_qubits > 10 or not x.is_cuda or lin_up.weight.shape[0] != x.shape[1]:
+            return None
+        quantum = not self.detach_quantum
+        res = _c.train_step(circ, x, noise, schedule, goal, lin_down.weight, lin_down.bias,
+                            angles.reshape(circ.angles_shape), lin_up.weight, lin_up.bias, quantum,
+                            want_recon=want_recon, want_elem_loss=want_elem_loss)
+        pairs = [(lin_up.weight, res["w_up"]), (lin_up.bias, res["b_up"])]
+        if quantum:
+            pairs += [(lin_down.weight, res["w_down"]), (lin_down.bias, res["b_down"]), (angles, res["angles"])]
+        for prm, g in pairs:
+            if prm is None or not prm.requires_grad:
+                continue
+            g = g.to(prm.dtype).view_as(prm)
+            prm.grad = g if prm.grad is None else prm.grad + g
+        return res
+
 
 # ===========================================================================
 # A4: amplitude embedding + SEL(CNOT) + probs
@@ -221,6 +254,11 @@ class QNN_noise(_QuantumNet):
     def _circuit_descriptor(self):
         return _c.Circuit(n_qubits=self.hidden_features, encoding="rz", imprimitive="CZ", measure="expz",
                           n_rounds=1, n_blocks=1, sel_layers=self.qdepth)
+
+    def _train_family(self):
+        if type(self)._circuit is not QNN_noise._circuit:
+            return None
+        return self._circuit_descriptor(), self.linear_down, self.weights, self.linear_up
 
     def forward(self, x):
         b, c, w, h = x.shape
@@ -430,6 +468,14 @@ class _QIDDMBase(_QuantumNet):
             x = self.qnode(x, self.weights1[n])
             x = (x.detach() if self.detach_quantum else x).to(torch.float64)   # finding F1
         return x
+
+    def _train_family(self):
+        if self._use_pca or not hasattr(self, "linear_down") or type(self)._circuit is not _QIDDMBase._circuit \
+                or type(self).forward is not _QIDDMBase.forward:
+            return None
+        circ = _c.Circuit(n_qubits=self.hidden_features, encoding="rz", imprimitive="CZ", measure="expz",
+                          n_rounds=self.N, n_blocks=self.spectrum_layer, sel_layers=2)
+        return circ, self.linear_down, self.weights1, self.linear_up
 
     def fused_sample_steps(self, x, n_steps, goal, noise_factor=1.0):
         """n_steps bodies of Diffusion.sample in one launch; None when not applicable."""

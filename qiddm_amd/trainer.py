@@ -1,0 +1,136 @@
+"""Device-resident training step of the denoise loop.
+
+The reference step is ``opt.zero_grad(); diff(x, T, verbose); opt.step()`` (src/mnist_exm.py:179-182) with
+the noising, the ``(batch tau)`` re-indexing, the MSE and ``.backward()`` inside ``Diffusion``
+(src/models.py:44-104).  Run eagerly that is ~60 small launches plus a host-side normal draw per step, and at
+the benchmark shapes the launches, not the arithmetic, set the step time.  ``GraphedTrainStep`` records the
+whole step -- noising, net forward (HIP circuit kernels), loss, backward (adjoint / parameter-shift kernels),
+Adam -- once into HIP graphs and replays them:
+
+    step = GraphedTrainStep(diff, torch.optim.Adam(diff.parameters(), lr=..., capturable=True), x_example, T=10)
+    loss = step(x)            # same numbers as the eager step on the same noise
+
+* ``noise="reference"``: the N(0.5, 0.2) field is drawn float32 on the CPU generator exactly as
+  src/noise.py:113-115 does, then copied into the graph's static buffer (RNG-stream parity with an eager run).
+* ``noise="device"``: drawn by the device generator inside the graph (no host work per step; a different,
+  equally distributed stream).
+* world size > 1: forward+backward and the optimizer are two graphs with the flat-bucket gradient all-reduce
+  (``parallel.all_reduce_gradients``) between them -- the one exchange step of the path (section 8e).
+
+Nets with a host-side front-end (the PCA classes, finding F4) cannot be recorded; they raise at capture and
+the caller keeps the eager step.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import noise as _noise
+from . import parallel
+
+
+class _StaticNoise:
+    """``add_normal_noise_multiple`` reading its one normal draw from the recorder's static buffer; carries the
+    same ``noise_field`` / ``schedule`` markers, so a net's fused training step stays available."""
+
+    schedule = staticmethod(_noise.add_normal_noise_multiple.schedule)
+
+    def __init__(self, owner):
+        self.owner = owner
+
+    def noise_field(self, data):
+        return self.owner._noise_field(data)
+
+    def __call__(self, data, tau, decay_mod=1.0):
+        return _noise.add_normal_noise_multiple(data, tau, decay_mod, noise=self.owner._noise_field(data))
+
+
+class GraphedTrainStep:
+    def __init__(self, diff, optimizer, x_example, T=10, noise="reference", verbose=False, warmup=3):
+        if noise not in ("reference", "device"):
+            raise ValueError(f"noise must be 'reference' or 'device', got {noise!r}")
+        if not x_example.is_cuda:
+            raise RuntimeError("GraphedTrainStep records HIP graphs: the batch must live on the GPU")
+        for group in optimizer.param_groups:
+            if not group.get("capturable", False):
+                raise ValueError("construct the optimizer with capturable=True")
+        self.diff, self.opt, self.T, self.noise_mode, self.verbose = diff, optimizer, T, noise, verbose
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.x = x_example.detach().clone()
+        self.noise = torch.empty(self.x.shape, dtype=torch.float32, device=self.x.device)
+        self._draw_noise()
+        self._user_noise_f = diff.add_noise
+        params = [p for p in diff.parameters() if p.requires_grad]
+        saved_p = [p.detach().clone() for p in params]
+        # -- warm-up on a side stream (lazy workspaces, Adam state), then restore the initial parameters ----
+        # A capturable torch optimizer keeps its step counter as a device scalar of the *default* dtype and
+        # derives the bias corrections from it; with float32 that costs ~1e-5 relative in the first updates
+        # against the eager optimizer (which uses Python floats).  The model is float64 (finding F5), so the
+        # optimizer state is created under a float64 default.
+        all_f64 = all(p.dtype == torch.float64 for p in params)
+        prev_default = torch.get_default_dtype()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        try:
+            if all_f64:
+                torch.set_default_dtype(torch.float64)
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    self.opt.zero_grad(set_to_none=True)
+                    self._fwd_bwd()
+                    self.opt.step()
+        finally:
+            torch.set_default_dtype(prev_default)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for p, s in zip(params, saved_p):
+                p.copy_(s)
+            for st in self.opt.state.values():
+                for v in st.values():
+                    if torch.is_tensor(v):
+                        v.zero_()
+        # -- record -------------------------------------------------------------------------------------
+        self.opt.zero_grad(set_to_none=True)
+        self.g_fwd_bwd = torch.cuda.CUDAGraph()
+        self.g_opt = None
+        if self.world == 1:
+            with torch.cuda.graph(self.g_fwd_bwd):
+                self._result = self._fwd_bwd()
+                self.opt.step()
+        else:
+            with torch.cuda.graph(self.g_fwd_bwd):
+                self._result = self._fwd_bwd()
+            self.g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_opt, pool=self.g_fwd_bwd.pool()):
+                self.opt.step()
+        self._params = params
+
+    def _draw_noise(self):
+        if self.noise_mode == "reference":
+            self.noise.copy_(torch.normal(mean=0.5, std=0.2, size=tuple(self.x.shape)), non_blocking=True)
+
+    def _noise_field(self, data):
+        if self.noise_mode == "device":
+            self.noise.normal_(mean=0.5, std=0.2)
+        return self.noise
+
+    def _fwd_bwd(self):
+        self.diff.add_noise = _StaticNoise(self)
+        try:
+            return self.diff(x=self.x, T=self.T, verbose=self.verbose)
+        finally:
+            self.diff.add_noise = self._user_noise_f
+
+    def __call__(self, x):
+        """One optimizer step on ``x`` (same shape as the example batch).  Returns what ``diff(x, T, verbose)``
+        returns; the tensors are the graph's static outputs (overwritten by the next call)."""
+        if x.shape != self.x.shape:
+            raise ValueError(f"recorded for batch shape {tuple(self.x.shape)}, got {tuple(x.shape)}")
+        self.x.copy_(x, non_blocking=True)
+        self._draw_noise()
+        self.g_fwd_bwd.replay()
+        if self.g_opt is not None:
+            parallel.all_reduce_gradients(self._params)
+            self.g_opt.replay()
+        return self._result

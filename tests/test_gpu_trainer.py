@@ -1,0 +1,59 @@
+"""Recorded (HIP-graph) training step == the eager reference-order step on the same noise
+(SURVEY.md section 8f rank 1)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _make(detach, method, seed=7):
+    from qiddm_amd import models, nn, noise
+    torch.manual_seed(seed)
+    net = nn.QNN_noise(64, 4, 2, detach_quantum=detach)
+    net.qnode.diff_method = method
+    diff = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (8, 8),
+                            torch.nn.MSELoss()).to("cuda", dtype=torch.double).train()
+    return diff
+
+
+@pytest.mark.parametrize("detach,method", [(True, "parameter-shift"), (False, "adjoint"), (False, "parameter-shift")])
+def test_graphed_step_matches_eager(detach, method):
+    from qiddm_amd.trainer import GraphedTrainStep
+    xs = [torch.rand(6, 64, dtype=torch.double, device="cuda") for _ in range(3)]
+    # eager, the reference's order of calls
+    eager = _make(detach, method)
+    opt_e = torch.optim.Adam(eager.parameters(), lr=1e-2)
+    torch.manual_seed(123)
+    losses_e = []
+    for x in xs:
+        opt_e.zero_grad()
+        (loss,) = eager(x=x, T=5)
+        opt_e.step()
+        losses_e.append(loss.item())
+    # recorded
+    rec = _make(detach, method)
+    opt_r = torch.optim.Adam(rec.parameters(), lr=1e-2, capturable=True)
+    torch.manual_seed(99)          # the capture draws from the CPU generator too
+    step = GraphedTrainStep(rec, opt_r, xs[0], T=5, noise="reference")
+    torch.manual_seed(123)
+    losses_r = [step(x)[0].item() for x in xs]
+    assert losses_r == pytest.approx(losses_e, rel=1e-9, abs=1e-12)
+    for (k, a), (_, b) in zip(eager.state_dict().items(), rec.state_dict().items()):
+        assert torch.allclose(a, b, rtol=1e-7, atol=1e-10), k
+    if not detach:
+        assert not torch.equal(rec.net.weights, _make(detach, method).net.weights)   # the angles trained
+
+
+def test_device_noise_and_shape_check():
+    from qiddm_amd.trainer import GraphedTrainStep
+    diff = _make(True, "parameter-shift")
+    opt = torch.optim.Adam(diff.parameters(), lr=1e-2, capturable=True)
+    x = torch.rand(4, 64, dtype=torch.double, device="cuda")
+    step = GraphedTrainStep(diff, opt, x, T=5, noise="device")
+    l0 = step(x)[0].item()
+    l1 = step(x)[0].item()
+    assert l0 > 0 and l1 > 0 and l0 != l1
+    with pytest.raises(ValueError):
+        step(torch.rand(5, 64, dtype=torch.double, device="cuda"))
+    with pytest.raises(ValueError):
+        GraphedTrainStep(diff, torch.optim.Adam(diff.parameters(), lr=1e-2), x, T=5)

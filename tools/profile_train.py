@@ -1,0 +1,25 @@
+"""Run the recorded training step of the flagship a few hundred times (for rocprofv3 --kernel-trace --stats)."""
+import sys, time
+import torch
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from qiddm_amd import models, nn, noise
+from qiddm_amd.trainer import GraphedTrainStep
+
+mode = sys.argv[1] if len(sys.argv) > 1 else "adjoint"
+torch.manual_seed(42)
+net = nn.QNN_noise(784, 8, 14, detach_quantum=(mode == "detached"))
+if mode == "adjoint":
+    net.qnode.diff_method = "adjoint"
+diff = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (28, 28), torch.nn.MSELoss()).to("cuda", dtype=torch.double).train()
+x = torch.rand(256, 784, dtype=torch.double, device="cuda")
+step = GraphedTrainStep(diff, torch.optim.Adam(diff.parameters(), lr=1e-3, capturable=True), x, T=10, noise="device")
+for _ in range(5):
+    step(x)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(200):
+    step(x)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 200
+print(f"{mode}: {dt*1e6:.1f} us/step, {2560/dt/1e6:.2f} M img/s")
