@@ -271,6 +271,25 @@ int64_t qiddm_train_workspace_bytes(const qiddm_circuit_t *circ, int64_t batch, 
 int qiddm_train_step(const qiddm_circuit_t *circ, const qiddm_train_args_t *args, void *workspace,
                      int64_t workspace_bytes, void *stream);
 
+/* ---- Adam for every parameter tensor in one launch ------------------------------------------------
+ * torch.optim.Adam as the reference harness constructs it (src/mnist_exm.py:170; betas, eps, weight_decay
+ * passed explicitly; no amsgrad, no maximize):
+ *     step += 1;  g += weight_decay * p;  m.lerp_(g, 1-beta1);  v = beta2 v + (1-beta2) g^2
+ *     p -= lr / (1-beta1^step) * m / (sqrt(v) / sqrt(1-beta2^step) + eps)
+ * step: per-tensor device int64 counter (torch keeps one per parameter; read, then advanced by one at the
+ * end of the call); sync: device uint32 scratch, zero before the first call, left zero.  dtype per tensor QIDDM_F32/QIDDM_F64
+ * (grad and moments have the parameter's dtype; the arithmetic is float64).  Safe to record into a HIP graph. */
+typedef struct qiddm_adam_tensor {
+  void *param;
+  const void *grad;
+  void *exp_avg, *exp_avg_sq;
+  int64_t *step;
+  int64_t numel;
+  int32_t dtype, reserved;
+} qiddm_adam_tensor_t;
+int qiddm_adam_step(const qiddm_adam_tensor_t *tensors, int32_t n_tensors, double lr, double beta1,
+                    double beta2, double eps, double weight_decay, uint32_t *sync, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

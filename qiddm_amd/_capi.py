@@ -45,6 +45,7 @@ EXPORTS = (
     "qiddm_qconv_forward",
     "qiddm_train_workspace_bytes",
     "qiddm_train_step",
+    "qiddm_adam_step",
 )
 
 
@@ -118,6 +119,9 @@ def _declare(lib):
     lib.qiddm_train_workspace_bytes.argtypes = [P, i64, ctypes.c_int32, ctypes.c_int32]
     lib.qiddm_train_step.restype = ctypes.c_int
     lib.qiddm_train_step.argtypes = [P, ctypes.POINTER(TrainArgs), vp, i64, vp]
+    lib.qiddm_adam_step.restype = ctypes.c_int
+    lib.qiddm_adam_step.argtypes = [ctypes.POINTER(AdamTensor), ctypes.c_int32, ctypes.c_double, ctypes.c_double,
+                                    ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp]
 
 
 class TrainArgs(ctypes.Structure):
@@ -135,6 +139,14 @@ class TrainArgs(ctypes.Structure):
         ("g_w_up", ctypes.c_void_p), ("g_b_up", ctypes.c_void_p),
         ("recon", ctypes.c_void_p), ("elem_loss", ctypes.c_void_p),
     ]
+
+
+class AdamTensor(ctypes.Structure):
+    """``qiddm_adam_tensor_t``."""
+
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("step", ctypes.c_void_p), ("numel", ctypes.c_int64), ("dtype", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 def _preload_torch_hip_runtime():

@@ -101,7 +101,7 @@ int run_step(const qiddm_circuit_t* c, const qiddm_train_args_t* a, const Geomet
 
   // ---- 1a. projections (only the reverse sweep and linear_down consume them) ---------------------------------
   {
-    const int64_t units = a->batch * (a->tau + 1) + N + 2;
+    const int64_t units = a->batch * ((a->tau + qiddm::kProjLevels) / qiddm::kProjLevels) + N + 2;
     hipLaunchKernelGGL(qiddm::train_project_kernel<N>, dim3((unsigned)((units + 3) / 4)), dim3(4 * qiddm::kWave), 0,
                        st, a->x, a->noise, a->schedule, a->w_down, a->w_up, a->b_up,
                        reinterpret_cast<double*>(ws + g.off_proj), a->batch, d);
@@ -126,7 +126,7 @@ int run_step(const qiddm_circuit_t* c, const qiddm_train_args_t* a, const Geomet
 
   // ---- 2. weight-gradient partials ----------------------------------------------------------------------
   hipLaunchKernelGGL(qiddm::train_weight_grads_kernel<N>, dim3((unsigned)g.tiles, (unsigned)g.n_chunks),
-                     dim3(qiddm::kWave), 0, st, a->x, a->noise, a->schedule, a->w_up, a->b_up,
+                     dim3(qiddm::kGradWaves * qiddm::kWave), 0, st, a->x, a->noise, a->schedule, a->w_up, a->b_up,
                      reinterpret_cast<const double*>(ws + g.off_ev), reinterpret_cast<const double*>(ws + g.off_gxr),
                      reinterpret_cast<double*>(ws + g.off_partials), reinterpret_cast<double*>(ws + g.off_loss),
                      a->recon, a->elem_loss, a->batch, d);
@@ -213,6 +213,54 @@ int qiddm_train_step(const qiddm_circuit_t* circ, const qiddm_train_args_t* a, v
   unsigned char* ws = static_cast<unsigned char*>(workspace);
   hipStream_t st = static_cast<hipStream_t>(stream);
   return circ->dtype == QIDDM_F32 ? dispatch<float>(circ, a, g, ws, st) : dispatch<double>(circ, a, g, ws, st);
+}
+
+int qiddm_adam_step(const qiddm_adam_tensor_t* tensors, int32_t n_tensors, double lr, double beta1, double beta2,
+                    double eps, double weight_decay, uint32_t* sync, void* stream) {
+  if (n_tensors < 0) return fail(QIDDM_ERR_INVALID, "n_tensors < 0");
+  if (n_tensors > 0 && !tensors) return fail(QIDDM_ERR_INVALID, "tensors is NULL");
+  if (!sync) return fail(QIDDM_ERR_INVALID, "sync must not be NULL");
+  if (!(lr >= 0.0) || !(eps >= 0.0) || !(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0) ||
+      !(weight_decay >= 0.0))
+    return fail(QIDDM_ERR_INVALID, "Invalid Adam hyper-parameter (lr %g, betas %g/%g, eps %g, weight_decay %g)", lr,
+                beta1, beta2, eps, weight_decay);
+  for (int i = 0; i < n_tensors; ++i) {
+    const qiddm_adam_tensor_t& t = tensors[i];
+    if (t.numel < 1 || (t.dtype != QIDDM_F32 && t.dtype != QIDDM_F64))
+      return fail(QIDDM_ERR_INVALID, "tensor %d: bad numel/dtype", i);
+    if (!t.param || !t.grad || !t.exp_avg || !t.exp_avg_sq || !t.step)
+      return fail(QIDDM_ERR_INVALID, "tensor %d: NULL pointer", i);
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  for (int done = 0; done < n_tensors;) {  // batches of kAdamMaxTensors, each a self-contained launch
+    qiddm::AdamBatch a{};
+    int64_t blocks = 0;
+    int k = 0;
+    for (; k < qiddm::kAdamMaxTensors && done + k < n_tensors; ++k) {
+      const qiddm_adam_tensor_t& t = tensors[done + k];
+      a.param[k] = t.param;
+      a.grad[k] = t.grad;
+      a.exp_avg[k] = t.exp_avg;
+      a.exp_avg_sq[k] = t.exp_avg_sq;
+      a.step[k] = t.step;
+      a.numel[k] = t.numel;
+      a.is_f64[k] = t.dtype == QIDDM_F64;
+      blocks += (t.numel + 255) / 256;
+      a.block_end[k] = blocks;
+    }
+    done += k;
+    a.n_tensors = k;
+    a.lr = lr;
+    a.beta1 = beta1;
+    a.beta2 = beta2;
+    a.eps = eps;
+    a.weight_decay = weight_decay;
+    if (blocks > 0x7fffffff) return fail(QIDDM_ERR_UNSUPPORTED, "too many elements for one Adam launch");
+    hipLaunchKernelGGL(qiddm::adam_step_kernel, dim3((unsigned)blocks), dim3(256), 0, st, a, sync);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "adam_step_kernel launch failed: %s", hipGetErrorString(e));
+  }
+  return QIDDM_OK;
 }
 
 }  // extern "C"

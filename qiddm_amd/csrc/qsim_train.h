@@ -61,55 +61,70 @@ __device__ __forceinline__ double residual(int goal, double out, double noisy, d
 //                      = grad_scale * (0.1 (G ev + c)_j - 0.05 s_j - NU_j + CU_j)            goal "noise"
 // (NU / CU = the W_up projections of the noisy / clean row).
 // ---------------------------------------------------------------------------
+constexpr int kProjLevels = 4;  // noise levels per wavefront: each weight fetched once serves this many rows
+
 template <int N>
 __global__ __launch_bounds__(4 * kWave) void train_project_kernel(
     const double* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ sched,
     const double* __restrict__ wd, const double* __restrict__ wu, const double* __restrict__ bu,
     double* __restrict__ proj, int64_t batch, const TrainScalars d) {
+  constexpr int LG = kProjLevels;
   const int P = d.pixels;
   const int lane = threadIdx.x & (kWave - 1);
+  const int groups_per_sample = (d.T + 1 + LG - 1) / LG;
   const int64_t unit = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int64_t n_blend = batch * (d.T + 1);
+  const int64_t n_blend = batch * groups_per_sample;
   if (unit >= n_blend + N + 2) return;
   const int kind = unit < n_blend ? 0 : (int)(unit - n_blend) + 1;  // 0 blend, 1..N W_up column, N+1 b_up, N+2 ones
-  const int64_t b = kind == 0 ? unit / (d.T + 1) : 0;
-  const int t = kind == 0 ? (int)(unit - b * (d.T + 1)) : 0;
-  const float w = sched[t];
-  double acc[2 * N];
+  const int64_t b = kind == 0 ? unit / groups_per_sample : 0;
+  const int t0 = kind == 0 ? (int)(unit - b * groups_per_sample) * LG : 0;
+  float w[LG];
 #pragma unroll
-  for (int j = 0; j < 2 * N; ++j) acc[j] = 0.0;
-  constexpr int U = 8;
-  for (int p0 = lane; p0 < P; p0 += kWave * U) {
-    double v[U];
+  for (int l = 0; l < LG; ++l) w[l] = sched[t0 + l <= d.T ? t0 + l : d.T];
+  double acc[LG][2 * N];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int pix = p0 + u * kWave;
-      const int pc = pix < P ? pix : 0;
-      double val;
-      if (kind == 0) val = blend_noise(x[b * d.x_ld + pc], noise[b * d.noise_ld + pc], w);
-      else if (kind <= N) val = wu[(size_t)pc * N + (kind - 1)];
-      else if (kind == N + 1) val = bu ? bu[pc] : 0.0;
-      else val = 1.0;
-      v[u] = pix < P ? val : 0.0;
+  for (int l = 0; l < LG; ++l)
+#pragma unroll
+    for (int j = 0; j < 2 * N; ++j) acc[l][j] = 0.0;
+  for (int pix = lane; pix < P; pix += kWave) {
+    double wdv[N], wuv[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      wdv[j] = wd[(size_t)j * P + pix];
+      wuv[j] = wu[(size_t)pix * N + j];
     }
+    if (kind == 0) {
+      const double xv = x[b * d.x_ld + pix];
+      const float nz = noise[b * d.noise_ld + pix];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int pix = p0 + u * kWave;
-      const int pc = pix < P ? pix : 0;
+      for (int l = 0; l < LG; ++l) {
+        const double v = blend_noise(xv, nz, w[l]);
 #pragma unroll
-      for (int j = 0; j < N; ++j) {
-        if (kind == 0) acc[j] = fma(v[u], wd[(size_t)j * P + pc], acc[j]);
-        acc[N + j] = fma(v[u], wu[(size_t)pc * N + j], acc[N + j]);
+        for (int j = 0; j < N; ++j) {
+          acc[l][j] = fma(v, wdv[j], acc[l][j]);
+          acc[l][N + j] = fma(v, wuv[j], acc[l][N + j]);
+        }
       }
+    } else {
+      const double v = kind <= N ? wu[(size_t)pix * N + (kind - 1)] : (kind == N + 1 ? (bu ? bu[pix] : 0.0) : 1.0);
+#pragma unroll
+      for (int j = 0; j < N; ++j) acc[0][N + j] = fma(v, wuv[j], acc[0][N + j]);
     }
   }
-  double mine = 0.0;
 #pragma unroll
-  for (int j = 0; j < 2 * N; ++j) {
-    const double tot = group_sum<double, 6>(acc[j], lane);
-    mine = fma((double)(lane == j ? 1 : 0), tot, mine);
+  for (int l = 0; l < LG; ++l) {
+    double mine = 0.0;
+#pragma unroll
+    for (int j = 0; j < 2 * N; ++j) {
+      const double tot = group_sum<double, 6>(acc[l][j], lane);
+      mine = fma((double)(lane == j ? 1 : 0), tot, mine);
+    }
+    if (kind == 0) {
+      if (t0 + l <= d.T && lane < 2 * N) proj[(b * (d.T + 1) + t0 + l) * (2 * N) + lane] = mine;
+    } else if (l == 0 && lane < 2 * N) {
+      proj[(batch * (d.T + 1) + (kind - 1)) * (2 * N) + lane] = mine;
+    }
   }
-  if (lane < 2 * N) proj[unit * (2 * N) + lane] = mine;
 }
 
 template <typename T, int N>
@@ -256,14 +271,18 @@ __global__ __launch_bounds__(WPB* kWave, 2) void train_rows_kernel(
 // weight / bias gradient partials, loss partials, optional verbose outputs.  grid (pixel tiles, chunks), 64 threads.
 // partials layout [chunk][2n+1][P]: rows 0..n-1 dW_up[:, j], row n db_up, rows n+1.. dW_down[j, :]
 // ---------------------------------------------------------------------------
+constexpr int kGradWaves = 4;
+
 template <int N>
-__global__ __launch_bounds__(kWave) void train_weight_grads_kernel(
+__global__ __launch_bounds__(kGradWaves* kWave) void train_weight_grads_kernel(
     const double* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ sched,
     const double* __restrict__ wu, const double* __restrict__ bu, const double* __restrict__ ev,
     const double* __restrict__ gxr, double* __restrict__ partials, double* __restrict__ loss_partials,
     double* __restrict__ recon, double* __restrict__ elem, int64_t batch, const TrainScalars d) {
+  __shared__ double s_red[kGradWaves - 1][2 * N + 2][kWave];
   const int P = d.pixels;
-  const int pix = blockIdx.x * kWave + threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const int pix = blockIdx.x * kWave + lane;
   const bool pvalid = pix < P;
   const int pc = pvalid ? pix : 0;
   const int chunk = blockIdx.y;
@@ -279,7 +298,7 @@ __global__ __launch_bounds__(kWave) void train_weight_grads_kernel(
   }
   const double buv = bu ? bu[pc] : 0.0;
   double acc_bu = 0.0, loss = 0.0;
-  for (int64_t b = b0; b < b1; ++b) {
+  for (int64_t b = b0 + wave; b < b1; b += kGradWaves) {  // the chunk's samples are dealt to the waves
     const double xv = x[b * d.x_ld + pc];
     const float nz = noise[b * d.noise_ld + pc];
     double clean = blend_noise(xv, nz, sched[0]);
@@ -309,6 +328,28 @@ __global__ __launch_bounds__(kWave) void train_weight_grads_kernel(
       clean = noisy;
     }
   }
+  // waves 1.. hand their sums to wave 0 (fixed order)
+  if (wave > 0) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      s_red[wave - 1][j][lane] = acc_wu[j];
+      s_red[wave - 1][N + 1 + j][lane] = acc_wd[j];
+    }
+    s_red[wave - 1][N][lane] = acc_bu;
+    s_red[wave - 1][2 * N + 1][lane] = loss;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 0; w < kGradWaves - 1; ++w) {
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      acc_wu[j] += s_red[w][j][lane];
+      acc_wd[j] += s_red[w][N + 1 + j][lane];
+    }
+    acc_bu += s_red[w][N][lane];
+    loss += s_red[w][2 * N + 1][lane];
+  }
   if (pvalid) {
     double* dst = partials + (size_t)chunk * (2 * N + 1) * P + pix;
 #pragma unroll
@@ -319,8 +360,8 @@ __global__ __launch_bounds__(kWave) void train_weight_grads_kernel(
       for (int j = 0; j < N; ++j) dst[(size_t)(N + 1 + j) * P] = acc_wd[j];
     }
   }
-  loss = group_sum<double, 6>(pvalid ? loss : 0.0, threadIdx.x);
-  if (threadIdx.x == 0) loss_partials[(size_t)chunk * gridDim.x + blockIdx.x] = loss;
+  loss = group_sum<double, 6>(pvalid ? loss : 0.0, lane);
+  if (lane == 0) loss_partials[(size_t)chunk * gridDim.x + blockIdx.x] = loss;
 }
 
 // roles by workgroup: [0, wblocks) weight sums; wblocks: loss; n x db_down[j]; then one wavefront per Rot gate
@@ -377,6 +418,68 @@ __global__ __launch_bounds__(kWave) void train_finalize_kernel(
 #pragma unroll
   for (int i = 0; i < 8; ++i) k[i] = group_sum<double, 6>(k[i], lane);
   if (lane == 0) rot_grad_from_k(k, angles[g * 3 + 0], angles[g * 3 + 1], angles[g * 3 + 2], g_angles + g * 3);
+}
+
+// ---------------------------------------------------------------------------
+// Adam (torch.optim.Adam defaults of the reference harness, src/mnist_exm.py:170): every parameter tensor of the
+// model in ONE launch.  The per-tensor step counters (torch keeps one per parameter) live on the device so a
+// recorded graph advances them; the last workgroup to finish bumps them (every workgroup reads its counter
+// before signalling).
+// ---------------------------------------------------------------------------
+constexpr int kAdamMaxTensors = 16;
+struct AdamBatch {
+  void* param[kAdamMaxTensors];
+  const void* grad[kAdamMaxTensors];
+  void* exp_avg[kAdamMaxTensors];
+  void* exp_avg_sq[kAdamMaxTensors];
+  int64_t* step[kAdamMaxTensors];
+  int64_t block_end[kAdamMaxTensors];  // exclusive prefix of 256-element blocks
+  int64_t numel[kAdamMaxTensors];
+  int32_t is_f64[kAdamMaxTensors];
+  int32_t n_tensors;
+  double lr, beta1, beta2, eps, weight_decay;
+};
+
+template <typename T>
+__device__ __forceinline__ void adam_update(T* p, const T* g, T* m, T* v, int64_t i, const AdamBatch& a, double bc1,
+                                            double bc2_sqrt) {
+  double grad = (double)g[i];
+  const double prm = (double)p[i];
+  if (a.weight_decay != 0.0) grad = fma(a.weight_decay, prm, grad);
+  const double m0 = (double)m[i], v0 = (double)v[i];
+  const double m1 = m0 + (1.0 - a.beta1) * (grad - m0);               // exp_avg.lerp_(grad, 1 - beta1)
+  const double v1 = a.beta2 * v0 + (1.0 - a.beta2) * grad * grad;     // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+  const double denom = sqrt(v1) / bc2_sqrt + a.eps;
+  m[i] = (T)m1;
+  v[i] = (T)v1;
+  p[i] = (T)(prm - (a.lr / bc1) * (m1 / denom));
+}
+
+__global__ __launch_bounds__(256) void adam_step_kernel(const AdamBatch a, unsigned int* __restrict__ sync) {
+  int t = 0;
+  while (t < a.n_tensors - 1 && (int64_t)blockIdx.x >= a.block_end[t]) ++t;
+  const int64_t s = *a.step[t] + 1;
+  const double bc1 = 1.0 - pow(a.beta1, (double)s);
+  const double bc2_sqrt = sqrt(1.0 - pow(a.beta2, (double)s));
+  const int64_t first = t == 0 ? 0 : a.block_end[t - 1];
+  const int64_t i = ((int64_t)blockIdx.x - first) * 256 + threadIdx.x;
+  if (i < a.numel[t]) {
+    if (a.is_f64[t])
+      adam_update<double>(static_cast<double*>(a.param[t]), static_cast<const double*>(a.grad[t]),
+                          static_cast<double*>(a.exp_avg[t]), static_cast<double*>(a.exp_avg_sq[t]), i, a, bc1, bc2_sqrt);
+    else
+      adam_update<float>(static_cast<float*>(a.param[t]), static_cast<const float*>(a.grad[t]),
+                         static_cast<float*>(a.exp_avg[t]), static_cast<float*>(a.exp_avg_sq[t]), i, a, bc1, bc2_sqrt);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned int done = atomicAdd(sync, 1u);
+    if (done == gridDim.x - 1) {
+      for (int k = 0; k < a.n_tensors; ++k) *a.step[k] += 1;
+      *sync = 0u;
+    }
+  }
 }
 
 }  // namespace qiddm

@@ -7,7 +7,8 @@ the benchmark shapes the launches, not the arithmetic, set the step time.  ``Gra
 whole step -- noising, net forward (HIP circuit kernels), loss, backward (adjoint / parameter-shift kernels),
 Adam -- once into HIP graphs and replays them:
 
-    step = GraphedTrainStep(diff, torch.optim.Adam(diff.parameters(), lr=..., capturable=True), x_example, T=10)
+    step = GraphedTrainStep(diff, FusedAdam(diff.parameters(), lr=...), x_example, T=10)   # or torch's Adam
+                                                                                           # with capturable=True
     loss = step(x)            # same numbers as the eager step on the same noise
 
 * ``noise="reference"``: the N(0.5, 0.2) field is drawn float32 on the CPU generator exactly as
@@ -86,10 +87,13 @@ class GraphedTrainStep:
         with torch.no_grad():
             for p, s in zip(params, saved_p):
                 p.copy_(s)
-            for st in self.opt.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+            if hasattr(self.opt, "reset_state"):
+                self.opt.reset_state()
+            else:
+                for st in self.opt.state.values():
+                    for v in st.values():
+                        if torch.is_tensor(v):
+                            v.zero_()
         # -- record -------------------------------------------------------------------------------------
         self.opt.zero_grad(set_to_none=True)
         self.g_fwd_bwd = torch.cuda.CUDAGraph()

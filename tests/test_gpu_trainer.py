@@ -57,3 +57,51 @@ def test_device_noise_and_shape_check():
         step(torch.rand(5, 64, dtype=torch.double, device="cuda"))
     with pytest.raises(ValueError):
         GraphedTrainStep(diff, torch.optim.Adam(diff.parameters(), lr=1e-2), x, T=5)
+
+
+def test_fused_adam_matches_torch_adam():
+    from qiddm_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(8, 784), (8,), (14, 8, 3), (784, 8), (784,)] + [(5,)] * 14       # > 16 tensors: two launches
+    for dtype, tol in ((torch.float64, 1e-13), (torch.float32, 2e-6)):
+        a = [torch.randn(s, dtype=dtype, device="cuda").requires_grad_(True) for s in shapes]
+        b = [t.detach().clone().requires_grad_(True) for t in a]
+        oa = torch.optim.Adam(a, lr=0.01011, weight_decay=0.01)
+        ob = FusedAdam(b, lr=0.01011, weight_decay=0.01)
+        for it in range(5):
+            for ta, tb in zip(a, b):
+                g = torch.randn(ta.shape, dtype=dtype, device="cuda") * (10.0 ** -it)
+                ta.grad, tb.grad = g.clone(), g.clone()
+            a[1].grad = b[1].grad = None if it == 2 else a[1].grad     # a parameter without gradient is skipped
+            oa.step()
+            ob.step()
+        for ta, tb in zip(a, b):
+            assert torch.allclose(ta, tb, rtol=tol, atol=tol), (dtype, ta.shape)
+        assert set(ob.state[b[0]].keys()) == {"step", "exp_avg", "exp_avg_sq"}
+        assert ob.state[b[0]]["step"].item() == 5 and ob.state[b[1]]["step"].item() == 4
+    cpu = torch.zeros(3, requires_grad=True)
+    cpu.grad = torch.ones(3)
+    with pytest.raises(RuntimeError):
+        FusedAdam([cpu]).step()                       # no CPU path
+
+
+def test_graphed_step_with_fused_adam_matches_eager_torch_adam():
+    from qiddm_amd.optim import FusedAdam
+    from qiddm_amd.trainer import GraphedTrainStep
+    xs = [torch.rand(6, 64, dtype=torch.double, device="cuda") for _ in range(4)]
+    eager = _make(False, "adjoint")
+    opt_e = torch.optim.Adam(eager.parameters(), lr=1e-2)
+    torch.manual_seed(123)
+    losses_e = []
+    for x in xs:
+        opt_e.zero_grad()
+        (loss,) = eager(x=x, T=5)
+        opt_e.step()
+        losses_e.append(loss.item())
+    rec = _make(False, "adjoint")
+    step = GraphedTrainStep(rec, FusedAdam(rec.parameters(), lr=1e-2), xs[0], T=5, noise="reference")
+    torch.manual_seed(123)
+    losses_r = [step(x)[0].item() for x in xs]
+    assert losses_r == pytest.approx(losses_e, rel=1e-9, abs=1e-12)
+    for (k, a), (_, b) in zip(eager.state_dict().items(), rec.state_dict().items()):
+        assert torch.allclose(a, b, rtol=1e-7, atol=1e-10), k

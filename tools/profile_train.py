@@ -13,7 +13,8 @@ if mode == "adjoint":
     net.qnode.diff_method = "adjoint"
 diff = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (28, 28), torch.nn.MSELoss()).to("cuda", dtype=torch.double).train()
 x = torch.rand(256, 784, dtype=torch.double, device="cuda")
-step = GraphedTrainStep(diff, torch.optim.Adam(diff.parameters(), lr=1e-3, capturable=True), x, T=10, noise="device")
+from qiddm_amd.optim import FusedAdam
+step = GraphedTrainStep(diff, FusedAdam(diff.parameters(), lr=1e-3), x, T=10, noise="device")
 for _ in range(5):
     step(x)
 torch.cuda.synchronize()
