@@ -16,7 +16,8 @@ import threading
 import torch  # noqa: F401
 
 LIB_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libqiddm_hip.so")
+# QIDDM_HIP_LIB: load another build of the same ABI (kernel experiments); default is the in-tree library
+LIB_PATH = os.environ.get("QIDDM_HIP_LIB") or os.path.join(LIB_DIR, "libqiddm_hip.so")
 
 QIDDM_OK = 0
 ENC_NONE, ENC_AMPLITUDE, ENC_RZ, ENC_RY, ENC_RY_BLOCKS = 0, 1, 2, 3, 4

@@ -28,6 +28,12 @@
 #pragma once
 #include "qsim_adjoint.h"
 
+#ifndef QIDDM_TRAIN_OCC
+#define QIDDM_TRAIN_OCC 3  // waves per SIMD the reverse-sweep kernel is compiled for (register budget 512 / OCC);
+                           // measured at C2 (2560 rows): 1 -> 241 us, 2 -> 225, 3 -> 210 per step.  The forward-only
+                           // variant is fastest unconstrained (84 us vs 94-103)
+#endif
+
 namespace qiddm {
 
 struct TrainScalars {
@@ -140,7 +146,7 @@ __host__ __device__ inline size_t train_lds_bytes(int64_t n_rot_all, int n_round
 // 1b. the circuit, forward and (QUANTUM) reverse, one wavefront per row
 // ---------------------------------------------------------------------------
 template <typename T, int N, bool QUANTUM, int WPB>
-__global__ __launch_bounds__(WPB* kWave, 2) void train_rows_kernel(
+__global__ __launch_bounds__(WPB* kWave, QUANTUM ? QIDDM_TRAIN_OCC : 1) void train_rows_kernel(
     const double* __restrict__ proj, const double* __restrict__ bd, const double* __restrict__ angles,
     double* __restrict__ ev_out, double* __restrict__ gxr_out, T* __restrict__ k_partials, int64_t batch,
     const TrainScalars d, const KScalars p) {
