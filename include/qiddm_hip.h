@@ -290,6 +290,42 @@ typedef struct qiddm_adam_tensor {
 int qiddm_adam_step(const qiddm_adam_tensor_t *tensors, int32_t n_tensors, double lr, double beta1,
                     double beta2, double eps, double weight_decay, uint32_t *sync, void *stream);
 
+/* ---- eval-mode quantum convolution: circuit unitary + GEMM on the matrix cores ------------------------
+ * Reference nn/qconv.py:92-126: `_QConv2d_FAST.train(False)` caches `sample_matrix = qml.matrix(SEL(pi*tanh(w)))`
+ * and evaluates AmplitudeEmbedding -> QubitUnitary(sample_matrix) -> probs.
+ *
+ * qiddm_circuit_unitary: u (D, D) complex float64, row-major, interleaved (re, im): u[k][j] = <k|U|j> for the
+ * weight-only circuit StronglyEntanglingLayers(angles (1,1,S,n,3), imprimitive) -- circ->encoding / measure
+ * are ignored; n_rounds = n_blocks = 1, n_qubits <= 10.  Wire 0 is the most significant bit of k and j
+ * (qml.matrix(..., wire_order=range(n))).
+ *
+ * qiddm_qconv_unitary_forward: the same function of (x, weights) as qiddm_qconv_forward, computed as the
+ * implicit-im2col GEMM  (batch Ho Wo) x (C kh kw)  times  (C kh kw) x 2 C_out  on v_mfma_f32_32x32x2_f32
+ * (float32 products and sums) with the normalise / |.|^2 / scale / clamp epilogue; x, y float64 as there.
+ * workspace: qiddm_qconv_unitary_workspace_bytes (packed operand; rewritten by every call).
+ * Two neighbours of the convolution in `unet_simple` (reference nn/unet_simple.py:9-18, 40-49) can ride along:
+ *   upsample2x != 0: x is (batch, C, height, width) and the convolution reads its
+ *       torch.nn.Upsample(scale_factor=2, mode="bilinear") (align_corners=False) -- the `up_conv` pair;
+ *   bn != NULL: eval-mode BatchNorm2d on the output, (y - running_mean) / sqrt(running_var + eps) * weight + bias
+ *       (weight / bias may be NULL) -- the [QConv2d, BatchNorm2d] pair.                                */
+typedef struct qiddm_batchnorm {
+  const double *weight, *bias, *running_mean, *running_var; /* (out_channels) each */
+  double eps;
+} qiddm_batchnorm_t;
+int qiddm_circuit_unitary(const qiddm_circuit_t *circ, const double *angles, double *u, void *stream);
+int64_t qiddm_qconv_unitary_workspace_bytes(int32_t n_qubits, int64_t in_channels, int64_t kh, int64_t kw,
+                                            int64_t out_channels);
+int qiddm_qconv_unitary_forward(int32_t n_qubits, const double *u, const double *x, int64_t batch,
+                                int64_t in_channels, int64_t height, int64_t width, int64_t kh, int64_t kw,
+                                int64_t pad_h, int64_t pad_w, int64_t out_channels, int32_t upsample2x,
+                                const qiddm_batchnorm_t *bn, double *y, void *workspace,
+                                int64_t workspace_bytes, void *stream);
+
+/* classical 1x1 convolution, float64 NCHW (the UNets' `final_conv`, reference nn/unet.py:160-166):
+ * x (batch, in_channels, hw), weight (out_channels, in_channels), bias (out_channels) or NULL.          */
+int qiddm_conv1x1_forward(const double *x, const double *weight, const double *bias, int64_t batch,
+                          int64_t in_channels, int64_t out_channels, int64_t hw, double *y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,10 @@ EXPORTS = (
     "qiddm_train_workspace_bytes",
     "qiddm_train_step",
     "qiddm_adam_step",
+    "qiddm_circuit_unitary",
+    "qiddm_qconv_unitary_workspace_bytes",
+    "qiddm_qconv_unitary_forward",
+    "qiddm_conv1x1_forward",
 )
 
 
@@ -120,6 +124,15 @@ def _declare(lib):
     lib.qiddm_train_workspace_bytes.argtypes = [P, i64, ctypes.c_int32, ctypes.c_int32]
     lib.qiddm_train_step.restype = ctypes.c_int
     lib.qiddm_train_step.argtypes = [P, ctypes.POINTER(TrainArgs), vp, i64, vp]
+    lib.qiddm_circuit_unitary.restype = ctypes.c_int
+    lib.qiddm_circuit_unitary.argtypes = [P, vp, vp, vp]
+    lib.qiddm_qconv_unitary_workspace_bytes.restype = i64
+    lib.qiddm_qconv_unitary_workspace_bytes.argtypes = [ctypes.c_int32, i64, i64, i64, i64]
+    lib.qiddm_qconv_unitary_forward.restype = ctypes.c_int
+    lib.qiddm_qconv_unitary_forward.argtypes = [ctypes.c_int32, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64,
+                                                i64, ctypes.c_int32, ctypes.POINTER(BatchNormStruct), vp, vp, i64, vp]
+    lib.qiddm_conv1x1_forward.restype = ctypes.c_int
+    lib.qiddm_conv1x1_forward.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, vp]
     lib.qiddm_adam_step.restype = ctypes.c_int
     lib.qiddm_adam_step.argtypes = [ctypes.POINTER(AdamTensor), ctypes.c_int32, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp]
@@ -140,6 +153,13 @@ class TrainArgs(ctypes.Structure):
         ("g_w_up", ctypes.c_void_p), ("g_b_up", ctypes.c_void_p),
         ("recon", ctypes.c_void_p), ("elem_loss", ctypes.c_void_p),
     ]
+
+
+class BatchNormStruct(ctypes.Structure):
+    """``qiddm_batchnorm_t``."""
+
+    _fields_ = [("weight", ctypes.c_void_p), ("bias", ctypes.c_void_p), ("running_mean", ctypes.c_void_p),
+                ("running_var", ctypes.c_void_p), ("eps", ctypes.c_double)]
 
 
 class AdamTensor(ctypes.Structure):

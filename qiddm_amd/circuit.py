@@ -257,6 +257,99 @@ def dense_sample(circ: Circuit, x: torch.Tensor, w_down, b_down, angles, w_up, b
     return y
 
 
+def circuit_unitary(angles: torch.Tensor, n_qubits: int, imprimitive: str = "CNOT",
+                    precision: str = "f64") -> torch.Tensor:
+    """``qml.matrix`` of ``StronglyEntanglingLayers(angles (S, n, 3), imprimitive)`` with
+    ``wire_order=range(n)`` (reference nn/qconv.py:96-103): (D, D) complex128 on the device
+    (``qiddm_circuit_unitary``).  One wavefront per column; n <= 10."""
+    _require_device(angles, "the circuit weights")
+    device = angles.device
+    ang = _as_f64(angles, device)
+    circ = Circuit(n_qubits=n_qubits, encoding="none", imprimitive=imprimitive, measure="probs", n_rounds=1,
+                   n_blocks=1, sel_layers=ang.shape[0])
+    if tuple(ang.reshape(circ.angles_shape).shape) != circ.angles_shape:
+        raise ValueError(f"angles must have shape (S, {n_qubits}, 3); got {tuple(angles.shape)}")
+    d = 1 << n_qubits
+    u = torch.empty(d, d, 2, dtype=torch.float64, device=device)
+    cs = circ.c_struct(precision)
+    _capi.check(_capi.lib().qiddm_circuit_unitary(ctypes.byref(cs), ang.data_ptr(), u.data_ptr(),
+                                                  _stream_ptr(device)))
+    return torch.view_as_complex(u)
+
+
+_qconv_workspaces = {}
+
+
+def qconv_unitary_forward(x: torch.Tensor, unitary: torch.Tensor, n_qubits: int, out_channels: int, kernel_size,
+                          padding, upsample2x: bool = False, batch_norm: torch.nn.BatchNorm2d | None = None
+                          ) -> torch.Tensor:
+    """The eval-mode QConv2d forward (reference nn/qconv.py:105-113 + :58-69): unfold -> +0.1 ->
+    AmplitudeEmbedding(pad 0.5) -> QubitUnitary(unitary) -> probs -> post-processing, as one implicit-im2col GEMM
+    on the f32 matrix cores (``qiddm_qconv_unitary_forward``).  x (B, C, H, W) -> (B, out_channels, Ho, Wo)
+    float64; ``unitary`` (D, D) complex128 from ``circuit_unitary``.
+
+    ``upsample2x``: convolve ``Upsample(scale_factor=2, mode="bilinear")(x)`` without materialising it;
+    ``batch_norm``: apply this (eval-mode, running statistics) BatchNorm2d to the output in the epilogue."""
+    _require_device(unitary, "the circuit unitary")
+    _require_device(x, "the input batch")
+    device = unitary.device
+    b, c, h, w = x.shape
+    kh, kw = kernel_size
+    ph, pw = padding
+    d = 1 << n_qubits
+    if tuple(unitary.shape) != (d, d) or unitary.dtype != torch.complex128:
+        raise ValueError(f"unitary must be ({d}, {d}) complex128; got {tuple(unitary.shape)} {unitary.dtype}")
+    xx = _as_f64(x, device).contiguous()
+    ur = torch.view_as_real(unitary.contiguous())
+    lib = _capi.lib()
+    need = lib.qiddm_qconv_unitary_workspace_bytes(n_qubits, c, kh, kw, out_channels)
+    if need < 0:
+        _capi.check(int(need))
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _qconv_workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _qconv_workspaces[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    he, we = (2 * h, 2 * w) if upsample2x else (h, w)
+    ho, wo = he + 2 * ph - kh + 1, we + 2 * pw - kw + 1
+    y = torch.empty(b, out_channels, max(ho, 0), max(wo, 0), dtype=torch.float64, device=device)
+    bn_ref, keep = None, []
+    if batch_norm is not None:
+        if batch_norm.running_mean is None or batch_norm.running_var is None:
+            raise ValueError("the fused BatchNorm epilogue needs running statistics (eval mode)")
+
+        def f64(t):
+            if t is None:
+                return 0
+            t = _as_f64(t.detach(), device).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        bn_struct = _capi.BatchNormStruct(weight=f64(batch_norm.weight), bias=f64(batch_norm.bias),
+                                          running_mean=f64(batch_norm.running_mean),
+                                          running_var=f64(batch_norm.running_var), eps=float(batch_norm.eps))
+        bn_ref = ctypes.byref(bn_struct)
+    _capi.check(lib.qiddm_qconv_unitary_forward(n_qubits, ur.data_ptr(), xx.data_ptr(), b, c, h, w, kh, kw, ph, pw,
+                                                out_channels, int(bool(upsample2x)), bn_ref, y.data_ptr(),
+                                                ws.data_ptr(), ws.numel(), _stream_ptr(device)))
+    return y
+
+
+def conv1x1_forward(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
+    """Classical float64 1x1 convolution (``qiddm_conv1x1_forward``): x (B, C_in, H, W), weight (C_out, C_in, 1, 1)."""
+    _require_device(x, "the input batch")
+    device = x.device
+    xx = _as_f64(x, device).contiguous()
+    b, c, h, w = xx.shape
+    wt = _as_f64(weight.detach(), device).reshape(weight.shape[0], -1).contiguous()
+    if wt.shape[1] != c:
+        raise ValueError(f"weight expects {wt.shape[1]} input channels, x has {c}")
+    bs = None if bias is None else _as_f64(bias.detach(), device).contiguous()
+    y = torch.empty(b, wt.shape[0], h, w, dtype=torch.float64, device=device)
+    _capi.check(_capi.lib().qiddm_conv1x1_forward(xx.data_ptr(), wt.data_ptr(), 0 if bs is None else bs.data_ptr(), b,
+                                                  c, wt.shape[0], h * w, y.data_ptr(), _stream_ptr(device)))
+    return y
+
+
 _train_workspaces = {}
 
 

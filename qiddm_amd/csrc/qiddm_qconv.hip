@@ -1,0 +1,210 @@
+// qiddm_qconv.hip -- extern "C" entry points of the eval-mode quantum convolution (circuit unitary + MFMA GEMM);
+// device code in qsim_unitary.h.
+#include "capi_common.h"
+
+#include <hip/hip_runtime.h>
+
+#include "qsim_unitary.h"
+
+namespace {
+
+using qiddm_capi::check_circuit;
+using qiddm_capi::fail;
+using qiddm_capi::kMaxLds;
+
+int check_unitary_circuit(const qiddm_circuit_t* c) {
+  int rc = check_circuit(c);
+  if (rc != QIDDM_OK) return rc;
+  if (c->n_rounds != 1 || c->n_blocks != 1)
+    return fail(QIDDM_ERR_UNSUPPORTED, "the circuit unitary is defined for one round and one block of weight-only layers");
+  if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED)
+    return fail(QIDDM_ERR_UNSUPPORTED, "circuit unitary needs n_qubits <= %d (got %d)", QIDDM_MAX_QUBITS_FUSED,
+                c->n_qubits);
+  return QIDDM_OK;
+}
+
+template <typename T, int N>
+int launch_unitary(const qiddm_circuit_t* c, const double* angles, double* u, hipStream_t st) {
+  using L = qiddm::Layout<N>;
+  using S = qiddm::Smem<T, N>;
+  qiddm::KScalars p{};
+  p.batch = L::D;
+  p.encoding = 1;       // amplitude embedding of the one-hot rows
+  p.imprimitive = c->imprimitive;
+  p.measure = 0;
+  p.n_rounds = 1;
+  p.n_blocks = 1;
+  p.sel_layers = c->sel_layers;
+  p.n_features = L::D;
+  p.enc_scale = 1.0;
+  p.enc_offset = 0.0;
+  p.pad_with = 0.0;
+  const int waves = 4;
+  const int64_t n_rot = (int64_t)c->sel_layers * N;
+  const size_t smem = S::bytes(n_rot, c->imprimitive == QIDDM_IMP_CNOT, waves);
+  if (smem > kMaxLds)
+    return fail(QIDDM_ERR_UNSUPPORTED, "circuit with %lld Rot gates needs %zu B of LDS", (long long)n_rot, smem);
+  auto kern = qiddm::unitary_kernel<T, N>;
+  static bool big_lds_enabled = false;
+  if (smem > 48 * 1024 && !big_lds_enabled) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    if (ea != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
+    big_lds_enabled = true;
+  }
+  const int groups = (L::D + L::SPW - 1) / L::SPW;
+  const int blocks = (groups + waves - 1) / waves;
+  hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(waves * qiddm::kWave), smem, st, angles, u, p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "unitary_kernel<n=%d> launch failed: %s", N, hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
+template <typename T>
+int dispatch_unitary(const qiddm_circuit_t* c, const double* angles, double* u, hipStream_t st) {
+  switch (c->n_qubits) {
+    case 1: return launch_unitary<T, 1>(c, angles, u, st);
+    case 2: return launch_unitary<T, 2>(c, angles, u, st);
+    case 3: return launch_unitary<T, 3>(c, angles, u, st);
+    case 4: return launch_unitary<T, 4>(c, angles, u, st);
+    case 5: return launch_unitary<T, 5>(c, angles, u, st);
+    case 6: return launch_unitary<T, 6>(c, angles, u, st);
+    case 7: return launch_unitary<T, 7>(c, angles, u, st);
+    case 8: return launch_unitary<T, 8>(c, angles, u, st);
+    case 9: return launch_unitary<T, 9>(c, angles, u, st);
+    default: return launch_unitary<T, 10>(c, angles, u, st);
+  }
+}
+
+struct ConvGeometry {
+  int64_t ho, wo, m, k_pad, n_pad, off_w, off_padv, off_bn, total;
+};
+
+int conv_geometry(int n_qubits, int64_t batch, int64_t in_channels, int64_t height, int64_t width, int64_t kh,
+                  int64_t kw, int64_t pad_h, int64_t pad_w, int64_t out_channels, ConvGeometry* g) {
+  if (n_qubits < 1 || n_qubits > QIDDM_MAX_QUBITS)
+    return fail(QIDDM_ERR_INVALID, "n_qubits=%d out of range", n_qubits);
+  if (batch < 0 || in_channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad_h < 0 || pad_w < 0 ||
+      out_channels < 1)
+    return fail(QIDDM_ERR_INVALID, "bad convolution geometry");
+  const int64_t d = (int64_t)1 << n_qubits;
+  const int64_t f = in_channels * kh * kw;
+  if (f > d)
+    return fail(QIDDM_ERR_INVALID, "Features must be of length %lld or smaller; got length %lld.", (long long)d,
+                (long long)f);
+  g->ho = height + 2 * pad_h - kh + 1;
+  g->wo = width + 2 * pad_w - kw + 1;
+  if (g->ho < 1 || g->wo < 1) return fail(QIDDM_ERR_INVALID, "kernel larger than the padded image");
+  if (2 * out_channels > d && !(d == 2 && out_channels == 1))
+    return fail(QIDDM_ERR_INVALID, "out_channels=%lld exceeds the %lld even-index probabilities",
+                (long long)out_channels, (long long)(d / 2));
+  g->m = batch * g->ho * g->wo;
+  if (g->m >= ((int64_t)1 << 38)) return fail(QIDDM_ERR_INVALID, "too many output pixels");
+  g->k_pad = (f + qiddm::kGemmK - 1) / qiddm::kGemmK * qiddm::kGemmK;
+  g->n_pad = (out_channels + 31) / 32 * 64;
+  g->off_w = 0;
+  g->off_padv = (g->k_pad * g->n_pad * 4 + 255) / 256 * 256;
+  g->off_bn = g->off_padv + (g->n_pad * 4 + 255) / 256 * 256;
+  g->total = g->off_bn + (g->n_pad * 8 + 255) / 256 * 256;
+  return QIDDM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int qiddm_circuit_unitary(const qiddm_circuit_t* circ, const double* angles, double* u, void* stream) {
+  int rc = check_unitary_circuit(circ);
+  if (rc != QIDDM_OK) return rc;
+  if (!angles || !u) return fail(QIDDM_ERR_INVALID, "angles/u is NULL");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return circ->dtype == QIDDM_F32 ? dispatch_unitary<float>(circ, angles, u, st)
+                                  : dispatch_unitary<double>(circ, angles, u, st);
+}
+
+int64_t qiddm_qconv_unitary_workspace_bytes(int32_t n_qubits, int64_t in_channels, int64_t kh, int64_t kw,
+                                            int64_t out_channels) {
+  ConvGeometry g;
+  const int rc = conv_geometry(n_qubits, 1, in_channels, kh, kw, kh, kw, 0, 0, out_channels, &g);
+  if (rc != QIDDM_OK) return rc;
+  return g.total;
+}
+
+int qiddm_qconv_unitary_forward(int32_t n_qubits, const double* u, const double* x, int64_t batch,
+                                int64_t in_channels, int64_t height, int64_t width, int64_t kh, int64_t kw,
+                                int64_t pad_h, int64_t pad_w, int64_t out_channels, int32_t upsample2x,
+                                const qiddm_batchnorm_t* bn, double* y, void* workspace, int64_t workspace_bytes,
+                                void* stream) {
+  // with upsample2x the stored image is (height, width) and the convolution sees its bilinear x2
+  const int64_t h_eff = upsample2x ? 2 * height : height, w_eff = upsample2x ? 2 * width : width;
+  ConvGeometry g;
+  int rc = conv_geometry(n_qubits, batch, in_channels, h_eff, w_eff, kh, kw, pad_h, pad_w, out_channels, &g);
+  if (rc != QIDDM_OK) return rc;
+  if (batch == 0) return QIDDM_OK;
+  if (!u || !x || !y) return fail(QIDDM_ERR_INVALID, "u/x/y is NULL");
+  if (bn && (!bn->running_mean || !bn->running_var || !(bn->eps >= 0.0)))
+    return fail(QIDDM_ERR_INVALID, "batch norm needs running_mean / running_var and eps >= 0");
+  if (!workspace || workspace_bytes < g.total)
+    return fail(QIDDM_ERR_INVALID, "workspace of %lld B needed (qiddm_qconv_unitary_workspace_bytes), got %lld",
+                (long long)g.total, (long long)workspace_bytes);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned char* ws = static_cast<unsigned char*>(workspace);
+  float* w = reinterpret_cast<float*>(ws + g.off_w);
+  float* padv = reinterpret_cast<float*>(ws + g.off_padv);
+  double* bnv = reinterpret_cast<double*>(ws + g.off_bn);
+  const int d = 1 << n_qubits;
+  const int f = (int)(in_channels * kh * kw);
+  hipLaunchKernelGGL(qiddm::qconv_pack_kernel, dim3((unsigned)g.n_pad), dim3(256), 0, st, u, d, f,
+                     (int)out_channels, (int)g.k_pad, (int)g.n_pad, w, padv, bn ? bn->weight : nullptr,
+                     bn ? bn->bias : nullptr, bn ? bn->running_mean : nullptr, bn ? bn->running_var : nullptr,
+                     bn ? bn->eps : 0.0, bnv);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_pack_kernel launch failed: %s", hipGetErrorString(e));
+  qiddm::GemmConv gc{};
+  gc.C = (int32_t)in_channels;
+  gc.H = (int32_t)h_eff;
+  gc.W = (int32_t)w_eff;
+  gc.kh = (int32_t)kh;
+  gc.kw = (int32_t)kw;
+  gc.ph = (int32_t)pad_h;
+  gc.pw = (int32_t)pad_w;
+  gc.Ho = (int32_t)g.ho;
+  gc.Wo = (int32_t)g.wo;
+  gc.C_out = (int32_t)out_channels;
+  gc.F = f;
+  gc.K_pad = (int32_t)g.k_pad;
+  gc.N_pad = (int32_t)g.n_pad;
+  gc.upsample = upsample2x ? 1 : 0;
+  gc.Hs = (int32_t)height;
+  gc.Ws = (int32_t)width;
+  gc.has_bn = bn ? 1 : 0;
+  gc.M = g.m;
+  gc.pad_norm2 = 0.25 * (double)(d - f);
+  gc.post_scale = 0.5 * (double)d;
+  const int64_t mblocks = (g.m + qiddm::kGemmM - 1) / qiddm::kGemmM;
+  if (mblocks > 0x7fffffff) return fail(QIDDM_ERR_UNSUPPORTED, "too many output pixels for one launch");
+  hipLaunchKernelGGL(qiddm::qconv_gemm_kernel, dim3((unsigned)mblocks, (unsigned)(g.n_pad / 64)),
+                     dim3(4 * qiddm::kWave), 0, st, x, w, padv, bnv, y, gc);
+  e = hipGetLastError();
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_gemm_kernel launch failed: %s", hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
+int qiddm_conv1x1_forward(const double* x, const double* weight, const double* bias, int64_t batch,
+                          int64_t in_channels, int64_t out_channels, int64_t hw, double* y, void* stream) {
+  if (batch < 0 || in_channels < 1 || out_channels < 1 || hw < 0)
+    return fail(QIDDM_ERR_INVALID, "bad 1x1 convolution geometry");
+  if (batch == 0 || hw == 0) return QIDDM_OK;
+  if (!x || !weight || !y) return fail(QIDDM_ERR_INVALID, "x/weight/y is NULL");
+  if (in_channels > (1 << 20) || out_channels > (1 << 20)) return fail(QIDDM_ERR_UNSUPPORTED, "too many channels");
+  const int64_t total = batch * hw;
+  const int64_t blocks = (total + 255) / 256;
+  if (blocks > 0x7fffffff) return fail(QIDDM_ERR_UNSUPPORTED, "too many pixels for one launch");
+  hipLaunchKernelGGL(qiddm::conv1x1_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     weight, bias, y, total, hw, (int)in_channels, (int)out_channels);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "conv1x1_kernel launch failed: %s", hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
+}  // extern "C"

@@ -64,6 +64,10 @@ class QConv2d(torch.nn.Module):
         w_out = w_in + 2 * self.padding[1] - self.kernel_size[1] + 1
         if (not torch.is_grad_enabled() and self.qnode is self._own_qnode and self.wires <= 10
                 and 2 * self.out_channels <= 2 ** self.wires):
+            if not self.training and x.is_cuda:
+                # eval mode (reference :92-126): the cached circuit unitary, then one GEMM on the matrix cores
+                return _c.qconv_unitary_forward(x, self._eval_unitary(), self.wires, self.out_channels,
+                                                self.kernel_size, self.padding)
             # inference: unfold + embedding + circuit + post-processing in one launch
             return _c.qconv_forward(x, _qw_tanh(self.weights.detach().double()), self.wires,
                                     self.out_channels, self.kernel_size, self.padding)
@@ -71,6 +75,37 @@ class QConv2d(torch.nn.Module):
         feats = cols.transpose(1, 2).reshape(b * h_out * w_out, -1) + 0.1
         y = self._post_process(self.qnode(feats))                        # ((b h w), C_out)
         return y.reshape(b, h_out, w_out, -1).permute(0, 3, 1, 2).contiguous()
+
+    def eval_forward(self, x, upsample2x=False, batch_norm=None):
+        """Inference through the cached unitary + GEMM with the layer's ``unet_simple`` neighbours folded in
+        (``upsample2x``: the bilinear x2 in front of an ``up_conv``; ``batch_norm``: the eval-mode BatchNorm2d behind
+        a ``net`` convolution).  None when this layer or the call is outside that route."""
+        if torch.is_grad_enabled() or self.training or self.qnode is not self._own_qnode or not x.is_cuda \
+                or self.wires > 10 or 2 * self.out_channels > 2 ** self.wires or x.shape[1] != self.in_channels:
+            return None
+        if batch_norm is not None and (batch_norm.training or batch_norm.running_mean is None
+                                       or batch_norm.num_features != self.out_channels):
+            return None
+        return _c.qconv_unitary_forward(x, self._eval_unitary(), self.wires, self.out_channels, self.kernel_size,
+                                        self.padding, upsample2x=upsample2x, batch_norm=batch_norm)
+
+    def _eval_unitary(self):
+        """``sample_matrix`` of the reference (:96-103): the (D, D) complex128 matrix of
+        ``StronglyEntanglingLayers(pi*tanh(weights))``, rebuilt when the weights changed since it was taken."""
+        stamp = (self.weights._version, self.weights.data_ptr(), self.weights.device)
+        if self.sample_matrix is None or getattr(self, "_sample_stamp", None) != stamp:
+            self.sample_matrix = _c.circuit_unitary(_qw_tanh(self.weights.detach().double()), self.wires, "CNOT")
+            self._sample_stamp = stamp
+        return self.sample_matrix
+
+    def train(self, mode=True):
+        """Leaving eval mode drops the cached unitary, as the reference does (:123-125); entering it lets the
+        next forward build it (the reference builds it here, which needs the weights on the device already)."""
+        super().train(mode)
+        if mode:
+            self.sample_qnode = None
+            self.sample_matrix = None
+        return self
 
     def __repr__(self):
         return (f"QConv2d({self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, "
