@@ -66,18 +66,19 @@ __global__ __launch_bounds__(4 * kWave) void unitary_kernel(const double* __rest
 }
 
 // ---------------------------------------------------------------------------
-// operand packing: W[f][col] float32, K_pad x N_pad, col = ct*64 + {0..31: Re, 32..63: Im} of channel ct*32 + (col&31)
-//                  padv[col] = 0.5 * sum_{j >= F} (Re|Im) U[2c][j]
+// operand packing: W[f][col] float32, K_pad x N_pad, padv[col] = 0.5 * sum_{j >= F} (Re|Im) U[2c][j].
+//   wide   (C_out > 16): 64 columns per 32-channel tile: col = ct*64 + {0..31: Re, 32..63: Im} of channel ct*32 + (col&31)
+//   packed (C_out <= 16): 32 columns: {0..15: Re, 16..31: Im} of channel col & 15 -- one MFMA tile holds both parts
+// bn[c] / bn[bn_stride + c]: eval-mode BatchNorm folded to  y * scale + shift  per channel
 // ---------------------------------------------------------------------------
-//                  bn[col] / bn[N_pad + col]: eval-mode BatchNorm folded to  y * scale + shift  per channel
 __global__ void qconv_pack_kernel(const double* __restrict__ u, int D, int F, int C_out, int K_pad, int N_pad,
-                                  float* __restrict__ w, float* __restrict__ padv,
+                                  int packed, float* __restrict__ w, float* __restrict__ padv,
                                   const double* __restrict__ bn_weight, const double* __restrict__ bn_bias,
                                   const double* __restrict__ bn_mean, const double* __restrict__ bn_var, double bn_eps,
-                                  double* __restrict__ bn) {
+                                  double* __restrict__ bn, int bn_stride) {
   const int col = blockIdx.x;  // one workgroup per packed column
-  const int c = (col >> 6) * 32 + (col & 31);
-  const int part = (col >> 5) & 1;
+  const int c = packed ? (col & 15) : (col >> 6) * 32 + (col & 31);
+  const int part = packed ? (col >> 4) & 1 : (col >> 5) & 1;
   const bool live = c < C_out;
   for (int f = threadIdx.x; f < K_pad; f += blockDim.x)
     w[(size_t)f * N_pad + col] = (live && f < F) ? (float)u[((size_t)(2 * c) * D + f) * 2 + part] : 0.f;
@@ -99,14 +100,15 @@ __global__ void qconv_pack_kernel(const double* __restrict__ u, int D, int F, in
         scale = (bn_weight ? bn_weight[c] : 1.0) * inv;
         shift = (bn_bias ? bn_bias[c] : 0.0) - bn_mean[c] * scale;
       }
-      bn[(col >> 6) * 32 + (col & 31)] = scale;
-      bn[N_pad / 2 + (col >> 6) * 32 + (col & 31)] = shift;
+      bn[c] = scale;
+      bn[bn_stride + c] = shift;
     }
   }
 }
 
 struct GemmConv {
   int32_t C, H, W, kh, kw, ph, pw, Ho, Wo, C_out, F, K_pad, N_pad;
+  int32_t bn_stride, pad_;
   int32_t upsample, Hs, Ws, has_bn;  // upsample: the (C, H, W) input is the bilinear x2 of a stored (C, Hs, Ws)
   int64_t M;           // batch * Ho * Wo
   double pad_norm2;    // 0.25 * (D - F)
@@ -116,7 +118,7 @@ struct GemmConv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kGemmM = 128;  // output pixels per workgroup
-constexpr int kGemmK = 16;   // K chunk
+constexpr int kGemmK = 32;   // K chunk
 
 // torch.nn.Upsample(scale_factor=2, mode="bilinear") (align_corners=False) of one (Hs, Ws) plane at (ii, jj):
 // ATen area_pixel_compute_source_index with scale 0.5, float64 accumulation
@@ -132,28 +134,88 @@ __device__ __forceinline__ double bilinear2x(const double* __restrict__ plane, i
   return h0l * (w0l * r0[0] + w1l * r0[w1p]) + h1l * (w0l * r1[0] + w1l * r1[w1p]);
 }
 
+constexpr int kGemmMaxK = 1024;  // F <= D <= 2^10 on this route
+
+// PACKED: C_out <= 16, real and imaginary columns share one 32-wide tile (one accumulator, half the MFMAs)
+template <bool PACKED>
 __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __restrict__ x,
                                                                const float* __restrict__ w,
                                                                const float* __restrict__ padv,
                                                                const double* __restrict__ bn,
                                                                double* __restrict__ y, const GemmConv g) {
-  __shared__ float s_a[kGemmK][kGemmM];   // [k][m]: lanes 0-31 / 32-63 of an A read hit consecutive words
-  __shared__ float s_b[kGemmK][64];       // [k][col]
+  constexpr int NB = PACKED ? 32 : 64;   // B columns per workgroup
+  constexpr int CT = PACKED ? 16 : 32;   // channels per workgroup
+  constexpr int KT = kGemmK / 2;         // k values a staging thread owns per chunk
+  // LDS: the staging tiles of the K loop and the output tile of the epilogue share one region
+  constexpr int kStageBytes = (kGemmK * kGemmM + kGemmK * NB) * 4;
+  constexpr int kOutBytes = CT * (kGemmM + 1) * 8;
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[kOutBytes > kStageBytes ? kOutBytes : kStageBytes];
+  __shared__ int s_off[kGemmMaxK];            // feature f -> offset of its tap inside one image
+  __shared__ short s_di[kGemmMaxK], s_dj[kGemmMaxK];
   __shared__ float s_n2[2][kGemmM];
+  float (*s_a)[kGemmM] = reinterpret_cast<float (*)[kGemmM]>(s_raw);                       // [k][m]
+  float (*s_b)[NB] = reinterpret_cast<float (*)[NB]>(s_raw + kGemmK * kGemmM * 4);          // [k][col]
+  double (*s_out)[kGemmM + 1] = reinterpret_cast<double (*)[kGemmM + 1]>(s_raw);           // [channel][m]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * kGemmM;
-  const int ct = blockIdx.y;  // 32-channel tile
-  // ---- this thread's staging duty: row m_s, eight consecutive k of every chunk ------------------------
-  const int m_s = tid & (kGemmM - 1), kh_s = (tid >> 7) * 8;
+  const int ct = blockIdx.y;  // channel tile
+  const int khw = g.kh * g.kw;
+  const size_t plane = g.upsample ? (size_t)g.Hs * g.Ws : (size_t)g.H * g.W;
+  for (int f = tid; f < g.K_pad; f += 4 * kWave) {
+    const int c = f / khw, rem = f - c * khw;
+    const int di = rem / g.kw, dj = rem - di * g.kw;
+    s_off[f] = g.upsample ? c : (int)(c * plane) + di * g.W + dj;  // (upsample: the channel; taps are interpolated)
+    s_di[f] = (short)di;
+    s_dj[f] = (short)dj;
+  }
+  // ---- this thread's staging duty: row m_s, KT consecutive k of every chunk ------------------------------
+  const int m_s = tid & (kGemmM - 1), kh_s = (tid >> 7) * KT;
   const int64_t mg = m0 + m_s;
   const bool m_ok = mg < g.M;
   const int64_t pixels = (int64_t)g.Ho * g.Wo;
   const int64_t bi = m_ok ? mg / pixels : 0;
   const int pix = m_ok ? (int)(mg - bi * pixels) : 0;
   const int oi = pix / g.Wo - g.ph, oj = pix % g.Wo - g.pw;
-  const size_t plane = g.upsample ? (size_t)g.Hs * g.Ws : (size_t)g.H * g.W;
   const double* __restrict__ img = x + (size_t)bi * g.C * plane;
+  const double* __restrict__ corner = img + (int64_t)oi * g.W + oj;  // tap (0, 0) of channel 0 (not dereferenced if outside)
   float n2 = 0.f;
+  __syncthreads();
+
+  // registers of the chunk in flight: the gather for chunk k+1 is issued before the MFMAs of chunk k
+  double pv[KT];
+  float bv[(kGemmK * NB) / (4 * kWave)];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+      const int f = k0 + kh_s + u;
+      const int ii = oi + s_di[f], jj = oj + s_dj[f];
+      const bool in = m_ok && f < g.F && ii >= 0 && ii < g.H && jj >= 0 && jj < g.W;
+      pv[u] = 0.0;
+      if (in) pv[u] = g.upsample ? bilinear2x(img + (size_t)s_off[f] * plane, g.Hs, g.Ws, ii, jj) : corner[s_off[f]];
+    }
+#pragma unroll
+    for (int i = 0; i < (kGemmK * NB) / (4 * kWave); ++i) {
+      const int e = tid + i * 4 * kWave;
+      bv[i] = w[(size_t)(k0 + e / NB) * g.N_pad + ct * NB + (e % NB)];
+    }
+  };
+  auto stage = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+      const int f = k0 + kh_s + u;
+      float v = 0.f;
+      if (m_ok && f < g.F) {
+        v = (float)(pv[u] + 0.1);
+        n2 = fmaf(v, v, n2);
+      }
+      s_a[kh_s + u][m_s] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < (kGemmK * NB) / (4 * kWave); ++i) {
+      const int e = tid + i * 4 * kWave;
+      s_b[e / NB][e % NB] = bv[i];
+    }
+  };
 
   f32x16 acc_re, acc_im;
 #pragma unroll
@@ -161,60 +223,61 @@ __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __r
     acc_re[i] = 0.f;
     acc_im[i] = 0.f;
   }
-  const int khw = g.kh * g.kw;
+  fetch(0);
   for (int k0 = 0; k0 < g.K_pad; k0 += kGemmK) {
-    // stage A (im2col gather, + 0.1) and B
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int f = k0 + kh_s + u;
-      float v = 0.f;
-      if (m_ok && f < g.F) {
-        const int c = f / khw, rem = f - c * khw;
-        const int di = rem / g.kw, dj = rem - di * g.kw;
-        const int ii = oi + di, jj = oj + dj;
-        double pv = 0.0;
-        if (ii >= 0 && ii < g.H && jj >= 0 && jj < g.W)
-          pv = g.upsample ? bilinear2x(img + (size_t)c * plane, g.Hs, g.Ws, ii, jj) : img[((size_t)c * g.H + ii) * g.W + jj];
-        v = (float)(pv + 0.1);
-        n2 = fmaf(v, v, n2);
-      }
-      s_a[kh_s + u][m_s] = v;
-    }
-    for (int i = tid; i < kGemmK * 64; i += 4 * kWave)
-      s_b[i >> 6][i & 63] = w[(size_t)(k0 + (i >> 6)) * g.N_pad + ct * 64 + (i & 63)];
+    stage(k0);
     __syncthreads();
+    if (k0 + kGemmK < g.K_pad) fetch(k0 + kGemmK);
 #pragma unroll
     for (int kk = 0; kk < kGemmK; kk += 2) {
       const float a = s_a[kk + (lane >> 5)][wave * 32 + (lane & 31)];
       const float bre = s_b[kk + (lane >> 5)][lane & 31];
-      const float bim = s_b[kk + (lane >> 5)][32 + (lane & 31)];
       acc_re = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bre, acc_re, 0, 0, 0);
-      acc_im = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bim, acc_im, 0, 0, 0);
+      if constexpr (!PACKED) {
+        const float bim = s_b[kk + (lane >> 5)][32 + (lane & 31)];
+        acc_im = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bim, acc_im, 0, 0, 0);
+      }
     }
     __syncthreads();
   }
   s_n2[tid >> 7][m_s] = n2;
   __syncthreads();
+  // one division per pixel: D/2 over |a|^2
+  __shared__ double s_inv[kGemmM];
+  if (tid < kGemmM) s_inv[tid] = g.post_scale / ((double)s_n2[0][tid] + (double)s_n2[1][tid] + g.pad_norm2);
+  __syncthreads();
   // ---- epilogue: C/D map col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) ----------------
-  const int c = ct * 32 + (lane & 31);
-  if (c >= g.C_out) return;
-  const float pre = padv[ct * 64 + (lane & 31)], pim = padv[ct * 64 + 32 + (lane & 31)];
-  const double bn_scale = g.has_bn ? bn[c] : 1.0, bn_shift = g.has_bn ? bn[g.N_pad / 2 + c] : 0.0;
+  // |.|^2 / |a|^2 * D/2, clamp, BatchNorm -> the [channel][pixel] tile in LDS, then rows of consecutive pixels out
+  {
+    const int col = lane & 31;
+    const int cl = PACKED ? (col & 15) : col, c = ct * CT + cl;
+    const bool live = c < g.C_out;
+    const float pre = padv[ct * NB + cl], pim = padv[ct * NB + CT + cl];
+    const double bn_scale = (g.has_bn && live) ? bn[c] : 1.0, bn_shift = (g.has_bn && live) ? bn[g.bn_stride + c] : 0.0;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    const int ml = wave * 32 + row;
-    const int64_t m = m0 + ml;
-    if (m >= g.M) continue;
-    const double norm2 = (double)s_n2[0][ml] + (double)s_n2[1][ml] + g.pad_norm2;
-    const double re = (double)(acc_re[r] + pre), im = (double)(acc_im[r] + pim);
-    double v = (re * re + im * im) / norm2 * g.post_scale;
-    v = fmin(fmax(v, 0.0), 1.0);
-    if (g.has_bn) v = v * bn_scale + bn_shift;
-    const int64_t b = m / pixels;
-    const int64_t px = m - b * pixels;
-    y[((size_t)b * g.C_out + c) * pixels + px] = v;
+    for (int r = 0; r < 16; ++r) {
+      const int ml = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      float fre, fim;
+      if constexpr (PACKED) {
+        // lanes col < 16 hold Re of channel col, lanes col >= 16 hold Im of channel col - 16
+        const float other = __shfl_xor(acc_re[r], 16, kWave);
+        fre = col < 16 ? acc_re[r] : other;
+        fim = col < 16 ? other : acc_re[r];
+      } else {
+        fre = acc_re[r];
+        fim = acc_im[r];
+      }
+      const double re = (double)(fre + pre), im = (double)(fim + pim);
+      double v = (re * re + im * im) * s_inv[ml];
+      v = fmin(fmax(v, 0.0), 1.0);
+      if (!PACKED || col < 16) s_out[cl][ml] = v * bn_scale + bn_shift;
+    }
   }
+  __syncthreads();
+  if (!m_ok) return;
+  const int c_live = g.C_out - ct * CT < CT ? g.C_out - ct * CT : CT;
+  double* __restrict__ dst = y + ((size_t)bi * g.C_out + (size_t)ct * CT) * pixels + pix;
+  for (int cl = tid >> 7; cl < c_live; cl += 2) dst[(size_t)cl * pixels] = s_out[cl][m_s];
 }
 
 // ---------------------------------------------------------------------------
