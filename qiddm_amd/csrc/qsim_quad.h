@@ -24,79 +24,72 @@ struct QuadScalars {
   unsigned long long* stamps;  // diagnostics only (tools/stamp_dense.py)
 };
 
+// Rot = RZ(omega) RY(theta) RZ(phi), and everything between two RY layers is diagonal:
+//     RZ(phi^{l+1}) . CZ-ring^l . RZ(omega^l)        (x the data re-upload diagonal at a block start)
+// so the circuit runs as  [phase table] -> [RY on every wire] -> [phase table] -> ...  The phase of amplitude k
+// in front of layer l depends on the weights only; it is tabulated once per launch:
+//     t_lo[l][k & 255]  (bits 0..7, one entry per thread; for n = 8 the CZ sign is folded in)
+//     t_hi[l][k >> 8]   (register bits 8.., n > 8; the CZ sign then comes from the parity bits as before)
+// The diagonal after the last RY layer does not reach |amplitude|^2 and is dropped.  An RY has real entries:
+// a lane-bit gate is  c * own +- s * partner  (one packed multiply, one packed FMA, two floats of gate data).
 template <typename T, int N>
 struct QuadSmem {
   static constexpr int R = 1 << (N - 8);
-  __host__ __device__ static size_t gate_bytes(int64_t n_rot) { return (size_t)n_rot * kLdsGateReals * sizeof(T); }
+  __host__ __device__ static size_t ry_bytes(int64_t n_rot) { return (size_t)n_rot * 2 * sizeof(T); }
+  __host__ __device__ static size_t tlo_bytes(int64_t n_rot) { return (size_t)(n_rot / N) * 256 * 2 * sizeof(T); }
+  __host__ __device__ static size_t thi_bytes(int64_t n_rot) {
+    return ((size_t)(n_rot / N) * R * 2 * sizeof(T) + 15) / 16 * 16;
+  }
   static constexpr size_t kCzBytes = (size_t)(N - 1) * 256 * 4;
   static constexpr size_t kSlabBytes = (size_t)2 * 4 * R * kWave * 2 * sizeof(T);
   static constexpr size_t kMiscBytes = (4 * 16 + 16 + 16 + 16) * sizeof(double);
   __host__ __device__ static size_t bytes(int64_t n_rot) {
-    return gate_bytes(n_rot) + kCzBytes + kSlabBytes + kMiscBytes;
+    return (ry_bytes(n_rot) + 15) / 16 * 16 + tlo_bytes(n_rot) + thi_bytes(n_rot) + kCzBytes + kSlabBytes + kMiscBytes +
+           (size_t)n_rot * sizeof(double);  // staging scratch: the summed RZ angle per (layer, wire)
   }
 };
 
-// gate on lane bit Q (index bit Q, wire N-1-Q) in the quad layout
-template <typename T, int N, int Q>
-__device__ __forceinline__ void lane_bit_gate(const Engine<T, N - 2>& eng, V2<T> (&a)[1 << (N - 8)],
-                                              const T* s_gates, int gate0, int llane) {
-  using C = V2<T>;
-  constexpr int R = 1 << (N - 8);
-  const C* gp = reinterpret_cast<const C*>(s_gates + (size_t)(gate0 + (N - 1 - Q)) * kLdsGateReals);
-  if constexpr (Q >= 4 && R >= 2) {
-    C m[8];
+// RY(theta) on lane bit Q: own' = c own +- s partner ('+' on the lanes whose bit is set)
+template <int Q, typename T, int R>
+__device__ __forceinline__ void ry_lane(V2<T> (&a)[R], T c, T s_signed, int lane) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) m[i] = gp[i];
-    eng.template swap_reg0_with_lane_bit<Q>(a);
-    eng.template gate_regs<1>(a, m, m + 4);
-    eng.template swap_reg0_with_lane_bit<Q>(a);
-  } else {
-    const C* hp = gp + (((llane >> Q) & 1) << 2);
-    C h[4];
+  for (int r = 0; r < R; ++r) {
+    const V2<T> par = xlane2<(1 << Q), T>(a[r], lane);
+    a[r] = __builtin_elementwise_fma(bcast<T>(s_signed), par, bcast<T>(c) * a[r]);
+  }
+}
+// RY(theta) between register pairs (r, r | J)
+template <int J, typename T, int R>
+__device__ __forceinline__ void ry_regs(V2<T> (&a)[R], T c, T s) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) h[i] = hp[i];
-    eng.template gate_lane<Q>(a, h);
+  for (int r = 0; r < R; ++r) {
+    if ((r & J) == 0) {
+      const V2<T> a0 = a[r], a1 = a[r | J];
+      a[r] = __builtin_elementwise_fma(bcast<T>(-s), a1, bcast<T>(c) * a0);
+      a[r | J] = __builtin_elementwise_fma(bcast<T>(s), a0, bcast<T>(c) * a1);
+    }
   }
 }
 
-// all gate data one thread needs for one SEL layer, loaded together so that a single LDS round trip
-// (issued a layer ahead) covers the whole layer
+// what one thread needs for one layer, fetched a layer ahead
 template <typename T, int N>
-struct QuadLayerGates {
+struct QuadLayerData {
   using C = V2<T>;
-  static constexpr int NREG = N - 8;
-  C lane[6][4];                    // lane bits 0..5 without register partner: this lane's half
-  C full[2][8];                    // lane bits 4, 5 when exchanged with register bit 0 (R >= 2)
-  C reg[NREG > 0 ? NREG : 1][8];   // register bits 8..N-1
-  C w6[4], w7[4];                  // wave bits 6, 7: this wave's halves
+  static constexpr int R = 1 << (N - 8);
+  C ry[N];     // (cos, sin)(theta / 2) per WIRE
+  C tlo;       // this thread's phase
+  C thi[R];    // register-bit phases (n > 8)
+  uint32_t cz; // parity bits of the PREVIOUS layer's ring (n > 8)
 
-  __device__ __forceinline__ void load(const T* s_gates, int gate0, int llane, int wv) {
-    constexpr int R = 1 << (N - 8);
+  __device__ __forceinline__ void load(const C* s_ry, const C* s_tlo, const C* s_thi, const uint32_t* s_cz, int layer,
+                                       int prev_range, int tid) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      const C* gp = reinterpret_cast<const C*>(s_gates + (size_t)(gate0 + (N - 1 - q)) * kLdsGateReals);
-      if (q >= 4 && R >= 2) {
+    for (int w = 0; w < N; ++w) ry[w] = s_ry[layer * N + w];
+    tlo = s_tlo[layer * 256 + tid];
+    if constexpr (R > 1) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) full[q - 4][i] = gp[i];
-      } else {
-        const C* hp = gp + (((llane >> q) & 1) << 2);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) lane[q][i] = hp[i];
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NREG; ++j) {
-      const C* gp = reinterpret_cast<const C*>(s_gates + (size_t)(gate0 + (N - 1 - (8 + j))) * kLdsGateReals);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) reg[j][i] = gp[i];
-    }
-    const C* g6 = reinterpret_cast<const C*>(s_gates + (size_t)(gate0 + (N - 1 - 6)) * kLdsGateReals) + ((wv & 1) << 2);
-    const C* g7 = reinterpret_cast<const C*>(s_gates + (size_t)(gate0 + (N - 1 - 7)) * kLdsGateReals) +
-                  (((wv >> 1) & 1) << 2);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      w6[i] = g6[i];
-      w7[i] = g7[i];
+      for (int r = 0; r < R; ++r) thi[r] = s_thi[layer * R + r];
+      cz = prev_range >= 0 ? s_cz[prev_range * 256 + tid] : 0u;
     }
   }
 };
@@ -113,24 +106,28 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
   // PPT pixels per thread (in/out features <= 256 * PPT) stay in registers across the steps
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n_rot = p.n_rounds * p.n_blocks * p.sel_layers * N;
-  T* s_gates = reinterpret_cast<T*>(smem_raw);
-  uint32_t* s_cz = reinterpret_cast<uint32_t*>(smem_raw + QuadSmem<T, N>::gate_bytes(n_rot));
-  C* s_slab = reinterpret_cast<C*>(reinterpret_cast<unsigned char*>(s_cz) + QuadSmem<T, N>::kCzBytes);
-  double* s_part = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(s_slab) + QuadSmem<T, N>::kSlabBytes);
+  const int n_layers_all = n_rot / N;
+  using QS = QuadSmem<T, N>;
+  unsigned char* cursor = smem_raw;
+  C* s_ry = reinterpret_cast<C*>(cursor);
+  cursor += (QS::ry_bytes(n_rot) + 15) / 16 * 16;
+  C* s_tlo = reinterpret_cast<C*>(cursor);
+  cursor += QS::tlo_bytes(n_rot);
+  C* s_thi = reinterpret_cast<C*>(cursor);
+  cursor += QS::thi_bytes(n_rot);
+  uint32_t* s_cz = reinterpret_cast<uint32_t*>(cursor);
+  C* s_slab = reinterpret_cast<C*>(reinterpret_cast<unsigned char*>(s_cz) + QS::kCzBytes);
+  double* s_part = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(s_slab) + QS::kSlabBytes);
   double* s_xs = s_part + 4 * 16;  // [16] angles of the round
   double* s_cs = s_xs + 16;        // [16] cos(x/2)   (after the read-out: plain <Z_w>)
   double* s_sn = s_cs + 16;        // [16] sin(x/2)
+  double* s_alpha = s_sn + 16;     // [n_rot] staging only: phi^l_w + omega^{l-1}_w
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int llane = logical_lane(lane);
   const bool stamp = d.stamps != nullptr && blockIdx.x == 0 && tid == 0;
   if (stamp) d.stamps[0] = __builtin_amdgcn_s_memtime();
-  E eng;
-  eng.s_gates = s_gates;
-  eng.lane = lane;
-  eng.llane = llane;
-  eng.sub = llane;
   const int P = d.in_features, Q = d.out_features;
 
   // ---- issue every global load of the first sample BEFORE staging: their latency hides behind it ----
@@ -150,28 +147,65 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
     }
   }
 
-  // ---- staging: gate images from the raw angles, CZ sign bits per (range, thread) -----------------
-  for (int g = tid; g < n_rot; g += 256) {
-    const double phi = angles[g * 3 + 0], theta = angles[g * 3 + 1], omega = angles[g * 3 + 2];
-    double c, s, ca, sa, cb, sb;
-    table_sincos<T>(0.5 * theta, &s, &c);
-    table_sincos<T>(0.5 * (phi + omega), &sa, &ca);
-    table_sincos<T>(0.5 * (phi - omega), &sb, &cb);
-    E::put_gate(s_gates + (size_t)g * kLdsGateReals, (T)(ca * c), (T)(-sa * c), (T)(-cb * s), (T)(-sb * s),
-                (T)(cb * s), (T)(-sb * s), (T)(ca * c), (T)(sa * c));
-  }
+  // ---- staging: RY coefficients, phase tables, CZ parity bits ----------------------------------------------
+  const int layers_per_round = p.n_blocks * p.sel_layers;
   const uint32_t kbase = ((uint32_t)wv << 6) | (uint32_t)llane;  // index bits 0..7 of this thread
-  for (int rr = 1; rr < N; ++rr) {
-    uint32_t bits = 0;
-#pragma unroll
-    for (int r = 0; r < R; ++r) bits |= cz_ring_parity<N>(((uint32_t)r << 8) | kbase, rr) << r;
-    s_cz[(rr - 1) * 256 + tid] = bits;
+  for (int g = tid; g < n_rot; g += 256) {
+    double c, sn;
+    table_sincos<T>(0.5 * angles[g * 3 + 1], &sn, &c);
+    s_ry[g] = C{(T)c, (T)sn};
+    // the RZ(omega) of the layer before (same round) merges with this layer's RZ(phi)
+    const int li = (g / N) % layers_per_round;
+    s_alpha[g] = angles[g * 3 + 0] + (li > 0 ? angles[(g - N) * 3 + 2] : 0.0);
   }
+  __syncthreads();
+  for (int l = 0; l < n_layers_all; ++l) {
+    const int li = l % layers_per_round;
+    // RZ(alpha) = diag(e^{-i alpha/2}, e^{+i alpha/2}): the phases of all wires add up to one angle
+    double ang = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double al = s_alpha[l * N + (N - 1 - q)];
+      ang += ((kbase >> q) & 1u) ? 0.5 * al : -0.5 * al;
+    }
+    double c, sn;
+    table_sincos<T>(ang, &sn, &c);
+    if constexpr (R == 1) {
+      if (li > 0 && cz_ring_parity<N>(kbase, ((li - 1) % p.sel_layers) % (N - 1) + 1)) {
+        c = -c;
+        sn = -sn;
+      }
+    }
+    s_tlo[l * 256 + tid] = C{(T)c, (T)sn};
+  }
+  if constexpr (R > 1) {
+    for (int i = tid; i < n_layers_all * R; i += 256) {
+      const int l = i / R, r = i % R;
+      double ang = 0.0;
+#pragma unroll
+      for (int j = 0; j < N - 8; ++j) {
+        const double al = s_alpha[l * N + (N - 1 - (8 + j))];
+        ang += ((r >> j) & 1) ? 0.5 * al : -0.5 * al;
+      }
+      double c, sn;
+      table_sincos<T>(ang, &sn, &c);
+      s_thi[i] = C{(T)c, (T)sn};
+    }
+    for (int rr = 1; rr < N; ++rr) {
+      uint32_t bits = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) bits |= cz_ring_parity<N>(((uint32_t)r << 8) | kbase, rr) << r;
+      s_cz[(rr - 1) * 256 + tid] = bits;
+    }
+  }
+  // +-1 by this thread's index bit: the sign of sin in its row of RY
+  T pm[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) pm[q] = ((kbase >> q) & 1u) ? (T)1 : (T)-1;
   const double bd_mine = (bd && tid < N) ? bd[tid] : 0.0;
   __syncthreads();
   if (stamp) d.stamps[1] = __builtin_amdgcn_s_memtime();
 
-  const int layers_per_round = p.n_blocks * p.sel_layers;
   int xbuf_parity = 0;
   bool first = true;
   for (int64_t sample = blockIdx.x; sample < p.batch; sample += gridDim.x) {
@@ -223,9 +257,9 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
           s_cs[tid] = c;
           s_sn[tid] = s;
         }
-        // first layer's gates while the angles' sin/cos settle
-        QuadLayerGates<T, N> cur;
-        cur.load(s_gates, round * layers_per_round * N, llane, wv);
+        // first layer's data while the angles' sin/cos settle
+        QuadLayerData<T, N> cur;
+        cur.load(s_ry, s_tlo, s_thi, s_cz, round * layers_per_round, -1, tid);
         __syncthreads();
         // per-sample RZ diagonal of this thread's amplitudes
         C dx[R];
@@ -258,58 +292,54 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
 
         for (int li = 0; li < layers_per_round; ++li) {
           const int s = li % p.sel_layers;
-          if (s == 0) {  // block start: data re-upload
+          // ---- everything diagonal in front of this layer's RYs: one complex multiply per amplitude ----
 #pragma unroll
-            for (int r = 0; r < R; ++r) a[r] = cmul2<T>(dx[r], a[r], times_i<T>(a[r]));
+          for (int r = 0; r < R; ++r) {
+            C ph = cur.tlo;
+            if constexpr (R > 1) ph = cmul2<T>(cur.thi[r], ph, times_i<T>(ph));
+            if (s == 0) ph = cmul2<T>(dx[r], ph, times_i<T>(ph));  // block start: data re-upload
+            C v = cmul2<T>(ph, a[r], times_i<T>(a[r]));
+            if constexpr (R > 1) {
+              const uint32_t sb = ((cur.cz >> r) & 1u) << 31;  // CZ ring of the previous layer
+              v = C{flip_sign(v.x, sb), flip_sign(v.y, sb)};
+            }
+            a[r] = v;
           }
-          // wire w <-> index bit N-1-w.  Register bits, lane bits, then the wave pair.
-          if constexpr (N > 8) eng.template gate_regs<1>(a, cur.reg[0], cur.reg[0] + 4);
-          if constexpr (N > 9) eng.template gate_regs<2>(a, cur.reg[N > 9 ? 1 : 0], cur.reg[N > 9 ? 1 : 0] + 4);
-          if constexpr (R >= 2) {
-            eng.template swap_reg0_with_lane_bit<5>(a);
-            eng.template gate_regs<1>(a, cur.full[1], cur.full[1] + 4);
-            eng.template swap_reg0_with_lane_bit<5>(a);
-            eng.template swap_reg0_with_lane_bit<4>(a);
-            eng.template gate_regs<1>(a, cur.full[0], cur.full[0] + 4);
-            eng.template swap_reg0_with_lane_bit<4>(a);
-          } else {
-            eng.template gate_lane<5>(a, cur.lane[5]);
-            eng.template gate_lane<4>(a, cur.lane[4]);
-          }
-          eng.template gate_lane<3>(a, cur.lane[3]);
-          eng.template gate_lane<2>(a, cur.lane[2]);
-          eng.template gate_lane<1>(a, cur.lane[1]);
-          eng.template gate_lane<0>(a, cur.lane[0]);
-          // ---- bits 6 and 7 together: new = sum_j M[wv][wv ^ j] * amp(wave wv ^ j) -------------------
-          const C a6 = cur.w6[0], b6 = cur.w6[2], a7 = cur.w7[0], b7 = cur.w7[2];  // own / partner coefficients
-          const C c0 = cmul2<T>(a7, a6, times_i<T>(a6));
-          const C c1 = cmul2<T>(a7, b6, times_i<T>(b6));
-          const C c2 = cmul2<T>(b7, a6, times_i<T>(a6));
-          const C c3 = cmul2<T>(b7, b6, times_i<T>(b6));
+          // ---- RY on every wire: wire w <-> index bit N-1-w.  Register bits, lane bits, then the wave pair ----
+          if constexpr (N > 8) ry_regs<1, T, R>(a, cur.ry[N - 1 - 8].x, cur.ry[N - 1 - 8].y);
+          if constexpr (N > 9) ry_regs<2, T, R>(a, cur.ry[N > 9 ? N - 1 - 9 : 0].x, cur.ry[N > 9 ? N - 1 - 9 : 0].y);
+          ry_lane<5, T, R>(a, cur.ry[N - 1 - 5].x, cur.ry[N - 1 - 5].y * pm[5], lane);
+          ry_lane<4, T, R>(a, cur.ry[N - 1 - 4].x, cur.ry[N - 1 - 4].y * pm[4], lane);
+          ry_lane<3, T, R>(a, cur.ry[N - 1 - 3].x, cur.ry[N - 1 - 3].y * pm[3], lane);
+          ry_lane<2, T, R>(a, cur.ry[N - 1 - 2].x, cur.ry[N - 1 - 2].y * pm[2], lane);
+          ry_lane<1, T, R>(a, cur.ry[N - 1 - 1].x, cur.ry[N - 1 - 1].y * pm[1], lane);
+          ry_lane<0, T, R>(a, cur.ry[N - 1 - 0].x, cur.ry[N - 1 - 0].y * pm[0], lane);
+          // ---- bits 6 and 7 together: new = sum_j M[wv][wv ^ j] * amp(wave wv ^ j),  M = RY_7 (x) RY_6 (real) ----
+          const T c6 = cur.ry[N - 1 - 6].x, t6 = cur.ry[N - 1 - 6].y * pm[6];
+          const T c7 = cur.ry[N - 1 - 7].x, t7 = cur.ry[N - 1 - 7].y * pm[7];
+          const T k0 = c7 * c6, k1 = c7 * t6, k2 = t7 * c6, k3 = t7 * t6;
           C* buf = s_slab + (size_t)xbuf_parity * (4 * R * kWave);
           xbuf_parity ^= 1;
 #pragma unroll
           for (int r = 0; r < R; ++r) buf[(wv * R + r) * kWave + lane] = a[r];
-          // next layer's gates: in flight across the barrier
+          // next layer's data: in flight across the barrier
           {
-            const int g_next = (round * layers_per_round + li + 1) * N;
-            cur.load(s_gates, g_next < n_rot ? g_next : 0, llane, wv);
+            const int l_next = round * layers_per_round + li + 1;
+            cur.load(s_ry, s_tlo, s_thi, s_cz, l_next < n_layers_all ? l_next : 0, s % (N - 1), tid);
           }
-          const uint32_t czbits = s_cz[(s % (N - 1)) * 256 + tid];
           __syncthreads();
 #pragma unroll
           for (int r = 0; r < R; ++r) {
             const C p1 = buf[((wv ^ 1) * R + r) * kWave + lane];
             const C p2 = buf[((wv ^ 2) * R + r) * kWave + lane];
             const C p3 = buf[((wv ^ 3) * R + r) * kWave + lane];
-            C o = cmul2<T>(a[r], c0, times_i<T>(c0));
-            o = cfma<T>(p1, c1, times_i<T>(c1), o);
-            o = cfma<T>(p2, c2, times_i<T>(c2), o);
-            o = cfma<T>(p3, c3, times_i<T>(c3), o);
-            const uint32_t sb = ((czbits >> r) & 1u) << 31;  // CZ ring
-            a[r] = C{flip_sign(o.x, sb), flip_sign(o.y, sb)};
+            C o = bcast<T>(k0) * a[r];
+            o = __builtin_elementwise_fma(bcast<T>(k1), p1, o);
+            o = __builtin_elementwise_fma(bcast<T>(k2), p2, o);
+            a[r] = __builtin_elementwise_fma(bcast<T>(k3), p3, o);
           }
         }
+        // (the ring and the RZ(omega) after the last RY layer are diagonal: they do not reach |amplitude|^2)
         // ---- <Z_w> -----------------------------------------------------------------------------------------------
         T ez[16];
 #pragma unroll
