@@ -202,6 +202,9 @@ def secondary_measurements(dev, batch):
             net = nn.QNN_noise(IMG * IMG, N_QUBITS, QDEPTH, detach_quantum=detach)
             if tag == "adjoint":
                 net.qnode.diff_method = "adjoint"     # the attribute the reference scripts poke
+            if tag == "parameter_shift":
+                net.fused_train_step = None           # the fused step always differentiates by the adjoint method:
+                                                      # keep the reference's declared diff_method measurable
             diff = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (IMG, IMG),
                                     torch.nn.MSELoss()).to(dev, dtype=torch.double).train()
             opt = torch.optim.Adam(diff.parameters(), lr=1e-3)
