@@ -326,6 +326,36 @@ int qiddm_qconv_unitary_forward(int32_t n_qubits, const double *u, const double 
 int qiddm_conv1x1_forward(const double *x, const double *weight, const double *bias, int64_t batch,
                           int64_t in_channels, int64_t out_channels, int64_t hw, double *y, void *stream);
 
+/* ---- density-matrix execution (hardware-noise study) ---------------------------------------------
+ * Replaces PennyLane's `default.mixed` for the circuits the `*_noise.py` drivers run at sampling time
+ * (src/mnist_noise.py:214-229; channels at nn/qdense.py:98-104, 255-261, 1410-1417).  The circuit is handed over
+ * as a program of single-wire / two-wire ops (the caller expands templates and entangler rings); one workgroup
+ * keeps one sample's rho (2^n x 2^n) in LDS or in `workspace`.  Forward only, n_qubits <= 8.
+ *   QIDDM_MIX_ZERO            rho = |0..0><0..0|                      (a program starts with ZERO or AMP_EMBED)
+ *   QIDDM_MIX_AMP_EMBED       AmplitudeEmbedding(features + enc_offset, pad_with, normalize)
+ *   QIDDM_MIX_PHASE           RZ / PhaseShift on `wire`: angle = p + scale * angle_rows[a][sample] (a < 0: p only)
+ *   QIDDM_MIX_RY              RY on `wire`, angle as above
+ *   QIDDM_MIX_GATE            the 2x2 unitary gates[a] = (u00, u01, u10, u11) as (re, im) float64
+ *   QIDDM_MIX_CZ / _CNOT      control `wire`, target `a`
+ *   QIDDM_MIX_PHASE_DAMP / _AMP_DAMP / _DEPOL   PennyLane's PhaseDamping / AmplitudeDamping /
+ *                             DepolarizingChannel with probability p on `wire`
+ * program: HOST array (copied to the head of `workspace` on `stream`); angle_rows (n_rows, rows_ld >= batch),
+ * features (batch, feat_ld), gates (n_gates, 8), out (batch, 2^n | n) float64 DEVICE arrays.            */
+enum {
+  QIDDM_MIX_ZERO = 0, QIDDM_MIX_AMP_EMBED, QIDDM_MIX_PHASE, QIDDM_MIX_RY, QIDDM_MIX_GATE, QIDDM_MIX_CZ,
+  QIDDM_MIX_CNOT, QIDDM_MIX_PHASE_DAMP, QIDDM_MIX_AMP_DAMP, QIDDM_MIX_DEPOL
+};
+typedef struct qiddm_mixed_op {
+  int32_t kind, wire, a, reserved;
+  double p, scale;
+} qiddm_mixed_op_t;
+int64_t qiddm_mixed_workspace_bytes(int32_t n_qubits, int32_t dtype, int64_t batch, int32_t n_ops);
+int qiddm_mixed_forward(int32_t n_qubits, int32_t dtype, const qiddm_mixed_op_t *program, int32_t n_ops,
+                        const double *angle_rows, int64_t rows_ld, int32_t n_rows, const double *features,
+                        int64_t feat_ld, int32_t n_features, double enc_offset, double pad_with,
+                        const double *gates, int32_t n_gates, int32_t measure, int64_t batch, double *out,
+                        int64_t out_ld, void *workspace, int64_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,8 @@ EXPORTS = (
     "qiddm_qconv_unitary_workspace_bytes",
     "qiddm_qconv_unitary_forward",
     "qiddm_conv1x1_forward",
+    "qiddm_mixed_workspace_bytes",
+    "qiddm_mixed_forward",
 )
 
 
@@ -131,6 +133,12 @@ def _declare(lib):
     lib.qiddm_qconv_unitary_forward.restype = ctypes.c_int
     lib.qiddm_qconv_unitary_forward.argtypes = [ctypes.c_int32, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64,
                                                 i64, ctypes.c_int32, ctypes.POINTER(BatchNormStruct), vp, vp, i64, vp]
+    lib.qiddm_mixed_workspace_bytes.restype = i64
+    lib.qiddm_mixed_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, i64, ctypes.c_int32]
+    lib.qiddm_mixed_forward.restype = ctypes.c_int
+    lib.qiddm_mixed_forward.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(MixedOp), ctypes.c_int32, vp, i64,
+                                        ctypes.c_int32, vp, i64, ctypes.c_int32, ctypes.c_double, ctypes.c_double, vp,
+                                        ctypes.c_int32, ctypes.c_int32, i64, vp, i64, vp, i64, vp]
     lib.qiddm_conv1x1_forward.restype = ctypes.c_int
     lib.qiddm_conv1x1_forward.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, vp]
     lib.qiddm_adam_step.restype = ctypes.c_int
@@ -153,6 +161,16 @@ class TrainArgs(ctypes.Structure):
         ("g_w_up", ctypes.c_void_p), ("g_b_up", ctypes.c_void_p),
         ("recon", ctypes.c_void_p), ("elem_loss", ctypes.c_void_p),
     ]
+
+
+MIX_ZERO, MIX_AMP_EMBED, MIX_PHASE, MIX_RY, MIX_GATE, MIX_CZ, MIX_CNOT, MIX_PHASE_DAMP, MIX_AMP_DAMP, MIX_DEPOL = range(10)
+
+
+class MixedOp(ctypes.Structure):
+    """``qiddm_mixed_op_t``."""
+
+    _fields_ = [("kind", ctypes.c_int32), ("wire", ctypes.c_int32), ("a", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("p", ctypes.c_double), ("scale", ctypes.c_double)]
 
 
 class BatchNormStruct(ctypes.Structure):

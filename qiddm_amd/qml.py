@@ -168,14 +168,14 @@ class Device:
             raise DeviceError(f"Device {name} does not exist. Make sure the required plugin is installed.")
 
     def __repr__(self):
-        return f"<qiddm_amd HIP statevector device standing in for {self.short_name!r}, wires={self.num_wires}>"
+        kind = "density-matrix" if self.mixed else "statevector"
+        return f"<qiddm_amd HIP {kind} device standing in for {self.short_name!r}, wires={self.num_wires}>"
 
 
 def device(name, wires=1, **kwargs):
     """``qml.device(name, wires=n)``.  Every pure-state device name the reference uses maps
-    to the HIP statevector engine; ``default.mixed`` is accepted at construction (the noise
-    scripts create it, src/mnist_noise.py:223) but cannot execute (density matrices are
-    out of scope)."""
+    to the HIP statevector engine; ``default.mixed`` (the noise scripts create it,
+    src/mnist_noise.py:223) maps to the density-matrix kernel (``qiddm_amd.mixed``: forward only, n <= 8)."""
     return Device(name, wires, **kwargs)
 
 
@@ -208,6 +208,12 @@ class QNode:
     def __call__(self, *args, **kwargs):
         tape, ret = self._trace(args, kwargs)
         n = self.device.num_wires
+        if self.device.mixed:
+            # density-matrix execution (forward only; the reference samples, never trains, on default.mixed)
+            from . import mixed as _mixed
+            self.circuit = None
+            with torch.no_grad():
+                return _mixed.execute(tape, ret, n, self.precision)
         circ, x, angles, batched, as_list = _compile(tape, ret, n, self.device)
         self.circuit = circ
         out = _c.execute(circ, x, angles, self.precision, self.diff_method or "backprop")
@@ -235,11 +241,7 @@ def _same_view(a, b) -> bool:
 def _compile(tape, ret, n, dev):
     for op in tape:
         if op.hyper.get("channel"):
-            if not dev.mixed:
-                raise DeviceError(f"Gate {op.name} not supported on device {dev.short_name}")
-            raise NotImplementedError("default.mixed (density-matrix) execution is out of scope")
-    if dev.mixed:
-        raise NotImplementedError("default.mixed (density-matrix) execution is out of scope")
+            raise DeviceError(f"Gate {op.name} not supported on device {dev.short_name}")
 
     # measurement
     if isinstance(ret, _Measurement):
