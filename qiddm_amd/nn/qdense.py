@@ -25,6 +25,7 @@ import torch
 import torch.nn as nn
 
 from .. import circuit as _c
+from .. import pca as _pca
 from .. import qml
 
 
@@ -353,8 +354,8 @@ class differN_noise(_QuantumNet):
     def reduce(self, x):
         """Host-side PCA front-end, re-fit on every call as written (:456, finding F4)."""
         flat = x.reshape(x.shape[0], self.pixels)
-        red = self.pca.fit_transform(flat.cpu().detach().numpy())
-        return torch.tensor(red, dtype=torch.float32).to(next(self.parameters()).device)
+        red = _pca.fit_transform(self.pca, flat)
+        return red.to(torch.float32).to(next(self.parameters()).device)
 
     def forward_from_reduced(self, red):
         """Everything after the PCA (:464-472): the part that is parity-tested."""
@@ -452,8 +453,8 @@ class _QIDDMBase(_QuantumNet):
 
     def reduce(self, flat):
         if self._use_pca:
-            red = self.pca.fit_transform(flat.cpu().numpy())     # re-fit per call (F4)
-            return torch.tensor(red).to(self.linear_up.weight.device).to(self.linear_up.weight.dtype)
+            red = _pca.fit_transform(self.pca, flat)              # re-fit per call (F4)
+            return red.to(self.linear_up.weight.device).to(self.linear_up.weight.dtype)
         return self.linear_down(flat)
 
     def quantum_rounds(self, red):

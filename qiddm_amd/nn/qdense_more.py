@@ -12,6 +12,7 @@ import pickle
 import torch
 import torch.nn as nn
 
+from .. import pca as _pca
 from .. import qml
 from .qdense import _QIDDMBase, _QuantumNet, _pair, differN_noise
 
@@ -207,11 +208,11 @@ class QIDDM_PP_noise(_QIDDMBase):
 
     def forward(self, x):
         b, c, w, h = x.shape
-        red = self.pca.fit_transform(x.reshape(b, -1).cpu().numpy())
-        red = torch.tensor(red).to(self.weights1.device).to(self.weights1.dtype)
+        red = _pca.fit_transform(self.pca, x.reshape(b, -1))
+        red = red.to(self.weights1.device).to(self.weights1.dtype)
         ev = self.quantum_rounds(red)
-        restored = self.pca.inverse_transform(ev.reshape(b, -1).detach().cpu().numpy())
-        return torch.tensor(restored, device=x.device, dtype=x.dtype, requires_grad=True).view(b, c, w, h)
+        restored = _pca.inverse_transform(self.pca, ev.reshape(b, -1))
+        return restored.detach().to(device=x.device, dtype=x.dtype).requires_grad_(True).view(b, c, w, h)
 
     def __repr__(self):
         return (f"QIDDM_PP_noise(qlayer={self.spectrum_layer}, features={self.hidden_features}, "
@@ -242,14 +243,13 @@ class QIDDM_PP_old(_QIDDMBase):
         flat = x.reshape(b, -1)
         if self.pca is None:
             self.pca = PCA(n_components=2 * self.hidden_features)
-            self.pca.fit(flat.detach().cpu().numpy())
-        red = torch.tensor(self.pca.transform(flat.detach().cpu().numpy()), device=x.device, dtype=x.dtype,
-                           requires_grad=True)
+            _pca.fit(self.pca, flat)
+        red = _pca.transform(self.pca, flat).detach().to(device=x.device, dtype=x.dtype).requires_grad_(True)
         red = self.linear_down(self.batch_norm(red))
         ev = self.quantum_rounds(red).to(x.dtype)
         up = self.linear_up(ev).reshape(b, -1)
-        restored = self.pca.inverse_transform(up.detach().cpu().numpy())
-        return torch.tensor(restored, device=x.device, dtype=x.dtype, requires_grad=True).view(b, c, w, h)
+        restored = _pca.inverse_transform(self.pca, up)
+        return restored.detach().to(device=x.device, dtype=x.dtype).requires_grad_(True).view(b, c, w, h)
 
     def __repr__(self):
         return f"QIDDM_PP(qlayer={self.spectrum_layer}, features={self.hidden_features}, N={self.N})"
@@ -398,8 +398,8 @@ class QIDDM_A_differN_basePL(_QuantumNet):
 
     def forward(self, x):
         b, c, w, h = x.shape
-        red = self.pca.fit_transform(x.reshape(b, -1).cpu().numpy())
-        red = torch.tensor(red).to(x.device).to(x.dtype)
+        red = _pca.fit_transform(self.pca, x.reshape(b, -1))
+        red = red.to(x.device).to(x.dtype)
         return self.forward_from_reduced(red).reshape(b, c, w, h)
 
     def __repr__(self):
