@@ -109,7 +109,10 @@ int64_t qiddm_num_rot_gates(const qiddm_circuit_t *circ);
 /* gate applications per sample per forward, counted as SURVEY.md section 8a             */
 int64_t qiddm_gate_count(const qiddm_circuit_t *circ);
 /* elements (of circ->dtype) in the gate table qiddm_prepare_gates writes:
- * num_rot_gates * 7 variants * 8 reals                                                   */
+ * num_rot_gates * 7 variants * 8 reals, plus (n <= 10) the folded per-layer tables the forward of a
+ * CZ circuit runs on: per layer n (cos, sin)(theta/2) pairs and 2^min(n,6) + 2^max(n-6,0) phases
+ * exp(i sum +-(phi^l + omega^(l-1))/2) -- RZ(phi) RZ(omega) and the CZ ring between two RY layers
+ * are one diagonal                                                                       */
 int64_t qiddm_gate_table_elems(const qiddm_circuit_t *circ);
 /* replicas of a full parameter-shift sweep: 6*num_rot_gates (+ 2*n_blocks*n for the
  * input angles of RZ/RY encodings)                                                       */

@@ -64,7 +64,7 @@ def per_iteration(generated, real, kind):
                     g, r = generated[it, i].squeeze(), real[j].squeeze()
                     rng = g.max() - g.min()
                     if kind == "cos":
-                        vals.append(float(calculate_cos(generated[it, i], real[j])))
+                        vals.append(float(calculate_cos(generated[it, i], real[j]).reshape(-1)[0]))
                     elif kind == "ssim":
                         vals.append(structural_similarity(g, r, rng))
                     else:

@@ -260,10 +260,24 @@ int dispatch_qconv(int n, const double* x, const double* angles, double* y, cons
 }
 
 // ---- quad layout (4 waves per sample) dense sampler ---------------------------------------------------
+template <typename T>
+size_t quad_lds_bytes(int n, int64_t n_rot) {
+  switch (n) {
+    case 8: return qiddm::QuadSmem<T, 8>::bytes(n_rot);
+    case 9: return qiddm::QuadSmem<T, 9>::bytes(n_rot);
+    default: return qiddm::QuadSmem<T, 10>::bytes(n_rot);
+  }
+}
+
 bool quad_supported(const qiddm_circuit_t* c, int64_t in_features, int64_t out_features) {
-  return c->n_qubits >= 8 && c->n_qubits <= 10 && c->imprimitive == QIDDM_IMP_CZ &&
-         c->encoding == QIDDM_ENC_RZ && c->measure == QIDDM_MEAS_EXPZ && in_features <= 2048 &&
-         out_features <= 2048 && c->n_qubits > 1;
+  if (!(c->n_qubits >= 8 && c->n_qubits <= 10 && c->imprimitive == QIDDM_IMP_CZ &&
+        c->encoding == QIDDM_ENC_RZ && c->measure == QIDDM_MEAS_EXPZ && in_features <= 2048 && out_features <= 2048))
+    return false;
+  // its per-layer phase tables must fit in LDS (deep float64 circuits at n = 10 do not)
+  const int64_t n_rot = (int64_t)c->n_rounds * c->n_blocks * c->sel_layers * c->n_qubits;
+  const size_t lds = c->dtype == QIDDM_F32 ? quad_lds_bytes<float>(c->n_qubits, n_rot)
+                                           : quad_lds_bytes<double>(c->n_qubits, n_rot);
+  return lds <= kMaxLds;
 }
 
 template <typename T, int N>
@@ -450,6 +464,9 @@ qiddm::KScalars make_params(const qiddm_circuit_t* c) {
   p.enc_scale = c->enc_scale;
   p.enc_offset = c->enc_offset;
   p.pad_with = c->pad_with;
+  // QIDDM_NO_FOLD=1: keep the general gate-by-gate forward (kernel experiments)
+  static const bool no_fold = std::getenv("QIDDM_NO_FOLD") != nullptr;
+  p.fold = (!no_fold && qiddm::can_fold(c->imprimitive, c->encoding)) ? 1 : 0;
   return p;
 }
 
@@ -489,9 +506,16 @@ int64_t qiddm_gate_count(const qiddm_circuit_t* c) {
   return g;
 }
 
+// entries (complex numbers) of the folded per-layer tables appended to the gate table (n <= 10 only)
+static int64_t fold_entries(const qiddm_circuit_t* c, int64_t n_rot) {
+  if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED) return 0;
+  const int n = c->n_qubits, lb = n < 6 ? n : 6;
+  return (n_rot / n) * (n + ((int64_t)1 << lb) + ((int64_t)1 << (n - lb)));
+}
+
 int64_t qiddm_gate_table_elems(const qiddm_circuit_t* c) {
   const int64_t g = qiddm_num_rot_gates(c);
-  return g < 0 ? g : g * qiddm::kVariants * qiddm::kGateReals;
+  return g < 0 ? g : g * qiddm::kVariants * qiddm::kGateReals + 2 * fold_entries(c, g);
 }
 
 int64_t qiddm_num_shift_replicas(const qiddm_circuit_t* c, int with_inputs) {
@@ -509,15 +533,17 @@ int qiddm_prepare_gates(const qiddm_circuit_t* c, const double* angles, void* ga
   if (rc != QIDDM_OK) return rc;
   if (!angles || !gate_table) return fail(QIDDM_ERR_INVALID, "angles/gate_table is NULL");
   const int64_t n_rot = (int64_t)c->n_rounds * c->n_blocks * c->sel_layers * c->n_qubits;
-  const int64_t total = n_rot * qiddm::kVariants;
+  const int64_t fe = fold_entries(c, n_rot);
+  const int64_t total = n_rot * qiddm::kVariants + fe;
   const unsigned blocks = (unsigned)((total + 255) / 256);
+  const int lpr = c->n_blocks * c->sel_layers;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (c->dtype == QIDDM_F32)
     hipLaunchKernelGGL(qiddm::prepare_gates_kernel<float>, dim3(blocks), dim3(256), 0, st, angles,
-                       static_cast<float*>(gate_table), n_rot);
+                       static_cast<float*>(gate_table), n_rot, c->n_qubits, lpr, fe);
   else
     hipLaunchKernelGGL(qiddm::prepare_gates_kernel<double>, dim3(blocks), dim3(256), 0, st, angles,
-                       static_cast<double*>(gate_table), n_rot);
+                       static_cast<double*>(gate_table), n_rot, c->n_qubits, lpr, fe);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess)
     return fail(QIDDM_ERR_LAUNCH, "prepare_gates launch failed: %s", hipGetErrorString(e));

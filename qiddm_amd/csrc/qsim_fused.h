@@ -57,6 +57,7 @@ struct KScalars {
   int64_t in_ld, out_ld, g_ld, batch;
   int32_t first_replica;
   int32_t encoding, imprimitive, measure, n_rounds, n_blocks, sel_layers, n_features;
+  int32_t fold, pad_;  // fold: run the forward of a CZ circuit on the folded tables (host: can_fold())
   double enc_scale, enc_offset, pad_with;
 };
 
@@ -229,11 +230,49 @@ struct Smem {
   __host__ __device__ static size_t scratch_bytes(int waves) {
     return (size_t)waves * kWave * L::R * 2 * sizeof(T);
   }
-  __host__ __device__ static size_t gate_bytes(int64_t n_rot) { return (size_t)n_rot * kLdsGateReals * sizeof(T); }
+  // the gate region holds either the general gate images (16 reals per Rot) or, for CZ circuits, the folded
+  // per-layer tables (kFoldStride reals per layer): sized for the larger of the two
+  static constexpr int kFoldStride = 2 * (N + L::LPS + L::R);
+  static constexpr int kLayerReals = N * kLdsGateReals > kFoldStride ? N * kLdsGateReals : kFoldStride;
+  __host__ __device__ static size_t gate_bytes(int64_t n_rot) { return (size_t)(n_rot / N) * kLayerReals * sizeof(T); }
   __host__ __device__ static size_t bytes(int64_t n_rot, bool cnot, int waves) {
     return gate_bytes(n_rot) + kTableBytes + (cnot ? scratch_bytes(waves) : 0);
   }
 };
+
+// ---------------------------------------------------------------------------
+// Folded tables for CZ circuits.  Rot = RZ(omega) RY(theta) RZ(phi) and the CZ ring is diagonal, so everything
+// between two RY layers is one diagonal that depends on the weights only:
+//     RZ(phi^l) . [CZ ring^{l-1} . RZ(omega^{l-1})]        (the bracket only inside a round, li > 0)
+// Per layer (stride 2 (n + LPS + R) reals):  ry[w] = (cos, sin)(theta_w / 2);
+//     t_lo[k]  = exp(i sum_{q < LB} +-alpha_q / 2),  k = lane bits of the amplitude index;
+//     t_hi[r]  = the same over the register bits;      alpha_w = phi^l_w + omega^{l-1}_w.
+// The ring's sign stays in the parity bits.  The diagonal after the last RY layer of a round does not reach
+// |amplitude|^2 and is dropped.  entry e of a layer: [0, n) ry, [n, n + LPS) t_lo, then t_hi.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void folded_entry(const double* __restrict__ angles, int n, int lb, int layer, int li,
+                                             int e, T* __restrict__ dst) {
+  const int lps = 1 << lb;
+  double c, sn;
+  if (e < n) {
+    table_sincos<T>(0.5 * angles[((size_t)layer * n + e) * 3 + 1], &sn, &c);
+  } else {
+    const bool lo = e < n + lps;
+    const int k = lo ? e - n : e - n - lps;
+    const int q0 = lo ? 0 : lb, q1 = lo ? lb : n;
+    double ang = 0.0;
+    for (int q = q0; q < q1; ++q) {
+      const int w = n - 1 - q;
+      double al = angles[((size_t)layer * n + w) * 3 + 0];
+      if (li > 0) al += angles[((size_t)(layer - 1) * n + w) * 3 + 2];
+      ang += ((k >> (q - q0)) & 1) ? 0.5 * al : -0.5 * al;
+    }
+    table_sincos<T>(ang, &sn, &c);
+  }
+  dst[0] = (T)c;
+  dst[1] = (T)sn;
+}
 
 // ---------------------------------------------------------------------------
 // the engine: everything a wave needs to push its samples through the circuit
@@ -330,6 +369,97 @@ struct Engine {
           cz[i] = bits;
         }
       }
+    }
+  }
+
+  // -- folded tables (CZ circuits): built in the gate region, stride S::kFoldStride per layer ------------
+  __device__ __forceinline__ void fill_folded_from_angles(const double* __restrict__ angles, int n_layers_all,
+                                                          int layers_per_round) {
+    constexpr int E = N + LPS + R;
+    for (int i = threadIdx.x; i < n_layers_all * E; i += blockDim.x) {
+      const int l = i / E, e = i - l * E;
+      folded_entry<T>(angles, N, LB, l, l % layers_per_round, e, s_gates_w + (size_t)l * S::kFoldStride + 2 * e);
+    }
+  }
+  __device__ __forceinline__ void fill_folded_from_table(const T* __restrict__ tail, int n_layers_all) {
+    for (int i = threadIdx.x; i < n_layers_all * S::kFoldStride; i += blockDim.x) s_gates_w[i] = tail[i];
+  }
+  struct FoldedLayer {
+    C ry[N];
+    C tlo;
+    C thi[R];
+    uint32_t cz;
+  };
+  __device__ __forceinline__ void load_folded(int layer, int prev_range_index, FoldedLayer& f) const {
+    const C* base = reinterpret_cast<const C*>(s_gates + (size_t)layer * S::kFoldStride);
+#pragma unroll
+    for (int w = 0; w < N; ++w) f.ry[w] = base[w];
+    f.tlo = base[N + sub];
+    if constexpr (R > 1) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) f.thi[r] = base[N + LPS + r];
+    }
+    f.cz = (N > 1 && prev_range_index >= 0) ? s_cz[prev_range_index * kWave + llane] : 0u;
+  }
+  // RY(theta) on wire W with the coefficients (c, s): register pairs, swap trick or lane partner
+  template <int W>
+  __device__ __forceinline__ void ry_wires(C (&a)[R], const FoldedLayer& f) const {
+    if constexpr (W < N) {
+      constexpr int Q = N - 1 - W;
+      const T c = f.ry[W].x, s = f.ry[W].y;
+      if constexpr (kind_of<W>() == kReg) {
+        ry_pairs<(1 << (Q >= LB ? Q - LB : 0))>(a, c, s);
+      } else if constexpr (kind_of<W>() == kSwap) {
+        swap_reg0_with_lane_bit<Q>(a);
+        ry_pairs<1>(a, c, s);
+        swap_reg0_with_lane_bit<Q>(a);
+      } else {
+        const T sg = ((llane >> Q) & 1) ? s : -s;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const C par = xlane2<(1 << Q), T>(a[r], lane);
+          a[r] = __builtin_elementwise_fma(bcast<T>(sg), par, bcast<T>(c) * a[r]);
+        }
+      }
+      ry_wires<W + 1>(a, f);
+    }
+  }
+  template <int J>
+  __device__ __forceinline__ void ry_pairs(C (&a)[R], T c, T s) const {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if ((r & J) == 0) {
+        const C a0 = a[r], a1 = a[r | J];
+        a[r] = __builtin_elementwise_fma(bcast<T>(-s), a1, bcast<T>(c) * a0);
+        a[r | J] = __builtin_elementwise_fma(bcast<T>(s), a0, bcast<T>(c) * a1);
+      }
+    }
+  }
+  // all layers of one round on the folded tables; `first_layer` = index of the round's first layer
+  __device__ __forceinline__ void folded_round(const KScalars& p, C (&a)[R], const C (&dx)[R], int first_layer,
+                                               int n_layers_all) const {
+    const int layers = p.n_blocks * p.sel_layers;
+    FoldedLayer cur;
+    load_folded(first_layer, -1, cur);
+    for (int li = 0; li < layers; ++li) {
+      const int s = li % p.sel_layers;
+      FoldedLayer nxt;
+      {
+        const int ln = first_layer + li + 1;
+        load_folded(ln < n_layers_all ? ln : 0, N > 1 ? s % (N - 1) : -1, nxt);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        C ph = cur.tlo;
+        if constexpr (R > 1) ph = cmul2<T>(cur.thi[r], ph, times_i<T>(ph));
+        if (s == 0 && p.encoding == 2) ph = cmul2<T>(dx[r], ph, times_i<T>(ph));  // block start: data re-upload
+        C v = cmul2<T>(ph, a[r], times_i<T>(a[r]));
+        const uint32_t sb = ((cur.cz >> r) & 1u) << 31;  // CZ ring of the previous layer
+        a[r] = C{flip_sign(v.x, sb), flip_sign(v.y, sb)};
+      }
+      ry_wires<0>(a, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
     }
   }
 
@@ -560,16 +690,17 @@ struct Engine {
   // xs: input angles (already scaled) for RZ/RY encodings; amp_row: feature row for
   // amplitude embedding.  On return pr[] holds the probabilities of this lane's
   // amplitudes and, for the <Z> read-out, result[] the n expectation values.
+  // folded: the gate region holds the folded tables (CZ circuits, no RY data encoding, no parameter shift)
   template <typename Src>
   __device__ __forceinline__ void run(const KScalars& p, const Src& amp_src, T (&xs)[N],
-                                      const Shift& sh, T (&result)[N], T (&pr)[R]) const {
+                                      const Shift& sh, T (&result)[N], T (&pr)[R], bool folded = false) const {
     const bool use_cnot = p.imprimitive == 0;
     C a[R];
     C dx[R];
     T cs[N], sn[N];
     const int n_rot = p.n_rounds * p.n_blocks * p.sel_layers * N;
     C gate_m[8];  // matrix of the next wire-0 gate, prefetched one layer ahead
-    load_gate<0>(0, gate_m);
+    if (!folded) load_gate<0>(0, gate_m);
     for (int round = 0; round < p.n_rounds; ++round) {
       // ---- state preparation ---------------------------------------------------------
       if (p.encoding == 1) {
@@ -595,6 +726,9 @@ struct Engine {
       if (p.encoding == 2) rz_diagonal(cs, sn, dx);
 
       // ---- blocks -----------------------------------------------------------------------
+      if (folded) {
+        folded_round(p, a, dx, round * p.n_blocks * p.sel_layers, n_rot / N);
+      } else
       for (int blk = 0; blk < p.n_blocks; ++blk) {
         if (p.encoding == 2) {
 #pragma unroll
@@ -663,6 +797,9 @@ struct Engine {
   }
 };
 
+// CZ entanglers and no RY data encoding: the circuit can run on the folded tables
+__host__ __device__ inline bool can_fold(int imprimitive, int encoding) { return imprimitive == 1 && encoding <= 2; }
+
 // feature sources for the amplitude embedding
 template <typename T>
 struct RowSrc {  // a row of a (batch, features) matrix
@@ -719,7 +856,12 @@ __global__ __launch_bounds__(4 * kWave) void circuit_kernel(const T* __restrict_
   }
   E eng;
   eng.carve(smem_raw, n_rot);
-  eng.fill_gates_from_table(table, n_rot, shift_gate, shift_var);
+  // forward of a CZ circuit: the folded tables that qiddm_prepare_gates appended to the gate table
+  const bool folded = !SHIFT && p.fold != 0;
+  if (folded)
+    eng.fill_folded_from_table(table + (size_t)n_rot * kVariants * kGateReals, n_rot / N);
+  else
+    eng.fill_gates_from_table(table, n_rot, shift_gate, shift_var);
   eng.fill_rings(p.imprimitive == 0);
   __syncthreads();
   const int lane = eng.lane, sub = eng.sub;
@@ -743,7 +885,7 @@ __global__ __launch_bounds__(4 * kWave) void circuit_kernel(const T* __restrict_
       for (int j = 0; j < N; ++j) xs[j] = (T)0;
     }
     T result[N], pr[R];
-    eng.run(p, RowSrc<T>{inputs + sample * p.in_ld}, xs, sh, result, pr);
+    eng.run(p, RowSrc<T>{inputs + sample * p.in_ld}, xs, sh, result, pr, folded);
 
     if constexpr (!SHIFT) {
       if (p.measure == 0) {
@@ -812,7 +954,11 @@ __global__ __launch_bounds__(WPB * kWave) void dense_forward_kernel(
     for (int i = threadIdx.x; i < N * P; i += blockDim.x) s_wd[i] = wd[i];
     for (int i = threadIdx.x; i < N * Q; i += blockDim.x) s_wu[(size_t)(i % N) * Q + i / N] = wu[i];
   }
-  eng.fill_gates_from_angles(angles, n_rot);
+  const bool folded = p.fold != 0;
+  if (folded)
+    eng.fill_folded_from_angles(angles, n_rot / N, p.n_blocks * p.sel_layers);
+  else
+    eng.fill_gates_from_angles(angles, n_rot);
   eng.fill_rings(p.imprimitive == 0);
   __syncthreads();
   if (stamp) d.stamps[1] = __builtin_amdgcn_s_memtime();
@@ -862,7 +1008,7 @@ __global__ __launch_bounds__(WPB * kWave) void dense_forward_kernel(
     if (stamp) d.stamps[2] = __builtin_amdgcn_s_memtime();
     // ---- the circuit --------------------------------------------------------------------------
     T result[N], pr[R];
-    eng.run(p, NoSrc{}, xs, no_shift, result, pr);
+    eng.run(p, NoSrc{}, xs, no_shift, result, pr, folded);
     double ev[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) ev[j] = (double)result[j];
@@ -968,9 +1114,19 @@ __global__ __launch_bounds__(4 * kWave) void qconv_forward_kernel(const double* 
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ void prepare_gates_kernel(const double* __restrict__ angles, T* __restrict__ table,
-                                     int64_t n_rot) {
+                                     int64_t n_rot, int n, int layers_per_round, int64_t fold_entries) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_rot * kVariants) return;
+  if (i >= n_rot * kVariants) {
+    // the folded tables of a register-resident circuit (n <= 10), appended after the gate variants
+    const int64_t j = i - n_rot * kVariants;
+    if (j >= fold_entries) return;
+    const int lb = n < 6 ? n : 6;
+    const int e_per_layer = n + (1 << lb) + (1 << (n - lb));
+    const int layer = (int)(j / e_per_layer), e = (int)(j - (int64_t)layer * e_per_layer);
+    folded_entry<T>(angles, n, lb, layer, layer % layers_per_round, e,
+                    table + n_rot * kVariants * kGateReals + (size_t)layer * 2 * e_per_layer + 2 * e);
+    return;
+  }
   const int64_t g = i / kVariants;
   const int v = (int)(i % kVariants);
   double ang[3] = {angles[g * 3 + 0], angles[g * 3 + 1], angles[g * 3 + 2]};

@@ -24,6 +24,7 @@ import math
 import torch
 import torch.nn as nn
 
+from .. import _capi
 from .. import circuit as _c
 from .. import pca as _pca
 from .. import qml
@@ -287,10 +288,15 @@ class QNN_noise(_QuantumNet):
         flat = x.reshape(b, -1).to(self.linear_down.weight.device).to(torch.double)
         if flat.shape[1] > 2048 or flat.shape[1] != self.linear_up.weight.shape[0]:
             return None
-        out = _c.dense_sample(circ, flat, self.linear_down.weight, self.linear_down.bias,
-                              self.weights.reshape(circ.angles_shape), self.linear_up.weight,
-                              self.linear_up.bias, n_steps, post_mode=0 if goal == "data" else 1,
-                              noise_factor=noise_factor)
+        try:
+            out = _c.dense_sample(circ, flat, self.linear_down.weight, self.linear_down.bias,
+                                  self.weights.reshape(circ.angles_shape), self.linear_up.weight,
+                                  self.linear_up.bias, n_steps, post_mode=0 if goal == "data" else 1,
+                                  noise_factor=noise_factor)
+        except _capi.QiddmError as e:
+            if e.code == -2:      # outside the fused sampler's range (e.g. tables beyond LDS): step by step
+                return None
+            raise
         return out.view(n_steps, b, c, w, h)
 
     def __repr__(self):
@@ -489,9 +495,14 @@ class _QIDDMBase(_QuantumNet):
             return None
         circ = _c.Circuit(n_qubits=self.hidden_features, encoding="rz", imprimitive="CZ", measure="expz",
                           n_rounds=self.N, n_blocks=self.spectrum_layer, sel_layers=2)
-        out = _c.dense_sample(circ, flat, self.linear_down.weight, self.linear_down.bias, self.weights1,
-                              self.linear_up.weight, self.linear_up.bias, n_steps,
-                              post_mode=0 if goal == "data" else 1, noise_factor=noise_factor)
+        try:
+            out = _c.dense_sample(circ, flat, self.linear_down.weight, self.linear_down.bias, self.weights1,
+                                  self.linear_up.weight, self.linear_up.bias, n_steps,
+                                  post_mode=0 if goal == "data" else 1, noise_factor=noise_factor)
+        except _capi.QiddmError as e:
+            if e.code == -2:      # outside the fused sampler's range: step by step
+                return None
+            raise
         return out.to(self.linear_up.weight.dtype).view(n_steps, b, c, w, h)
 
     def forward(self, x):

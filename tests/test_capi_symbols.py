@@ -40,7 +40,10 @@ def test_introspection_calls_need_no_gpu(hip_lib):
         cs = circ.c_struct("f32")
         assert hip_lib.qiddm_gate_count(ctypes.byref(cs)) == g == circ.gate_count()
         assert hip_lib.qiddm_num_rot_gates(ctypes.byref(cs)) == rot
-        assert hip_lib.qiddm_gate_table_elems(ctypes.byref(cs)) == rot * 56
+        n = circ.n_qubits
+        lb = min(n, 6)
+        folded = 0 if n > 10 else (rot // n) * 2 * (n + 2 ** lb + 2 ** (n - lb))   # per-layer tables for CZ circuits
+        assert hip_lib.qiddm_gate_table_elems(ctypes.byref(cs)) == rot * 56 + folded
     cs = cases[1][0].c_struct("f32")
     assert hip_lib.qiddm_num_shift_replicas(ctypes.byref(cs), 0) == 6 * 192
     assert hip_lib.qiddm_num_shift_replicas(ctypes.byref(cs), 1) == 6 * 192 + 2 * 6 * 8
