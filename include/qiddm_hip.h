@@ -170,7 +170,9 @@ int qiddm_forward_shifted(const qiddm_circuit_t *circ, const void *inputs, int64
  *                K_{ab} = sum conj(lambda_a) psi_b for every Rot gate (a,b in {0,1}, as re/im pairs in the
  *                order K00 K01 K10 K11); the caller sums them over dim 0 and contracts with the analytic
  *                dRot/d(phi,theta,omega):  dL/dangle = 2 Re sum_ab (dU/dangle)_ab K_ab.
- *                n_partials = qiddm_adjoint_partials(circ, batch).
+ *                n_partials = qiddm_adjoint_partials(circ, batch).  For CZ circuits without RY data encoding and
+ *                n <= 8 the slabs (same size) hold per-layer sums of d/dtheta and d/d(phi^l + omega^(l-1)) instead
+ *                (folded reverse sweep): treat them as opaque and hand them to qiddm_adjoint_finalize.
  *   grad_inputs: (batch, gin_ld) dL/d(inputs): n columns for RZ / RY encodings, n_features columns for
  *                the amplitude embedding (gradient through pad + normalise); may be NULL.
  * Cost: about five forward passes, independent of the number of parameters.                     */

@@ -689,6 +689,21 @@ int qiddm_adjoint_finalize(const qiddm_circuit_t* c, const double* angles, const
   const int64_t n_rot = (int64_t)c->n_rounds * c->n_blocks * c->sel_layers * c->n_qubits;
   const unsigned blocks = (unsigned)n_rot;  // one wavefront per gate
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (make_params(c).fold && c->n_qubits >= 2 && c->n_qubits <= qiddm::kFoldedAdjointMaxQubits) {
+    // the slabs hold per-layer angle-gradient sums (folded reverse sweep), not K
+    const int slots = c->n_qubits <= 8 ? 8 : 16;
+    if (c->dtype == QIDDM_F32)
+      hipLaunchKernelGGL(qiddm::adjoint_finalize_folded_kernel<float>, dim3(blocks), dim3(qiddm::kWave), 0, st,
+                         static_cast<const float*>(k_partials), n_partials, n_rot * 8, c->n_qubits,
+                         c->n_blocks * c->sel_layers, slots, n_rot, grad_angles);
+    else
+      hipLaunchKernelGGL(qiddm::adjoint_finalize_folded_kernel<double>, dim3(blocks), dim3(qiddm::kWave), 0, st,
+                         static_cast<const double*>(k_partials), n_partials, n_rot * 8, c->n_qubits,
+                         c->n_blocks * c->sel_layers, slots, n_rot, grad_angles);
+    const hipError_t ef = hipGetLastError();
+    if (ef != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "adjoint_finalize launch failed: %s", hipGetErrorString(ef));
+    return QIDDM_OK;
+  }
   if (c->dtype == QIDDM_F32)
     hipLaunchKernelGGL(qiddm::adjoint_finalize_kernel<float>, dim3(blocks), dim3(qiddm::kWave), 0, st,
                        static_cast<const float*>(k_partials), n_partials, n_rot, angles, grad_angles);

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "qsim_train.h"
 
 namespace {
@@ -97,6 +99,11 @@ int run_step(const qiddm_circuit_t* c, const qiddm_train_args_t* a, const Geomet
   d.want_elem = a->elem_loss != nullptr;
   d.grad_scale = (a->goal == 0 ? 2.0 : 0.2) / ((double)g.rows * (double)a->pixels);
   const bool q = d.train_quantum != 0;
+  static const bool no_fold = std::getenv("QIDDM_NO_FOLD") != nullptr;  // kernel experiments: general reverse sweep
+  d.fold = (q && !no_fold && qiddm::can_fold(c->imprimitive, c->encoding) && N >= 2 &&
+            N <= qiddm::kFoldedAdjointMaxQubits) ? 1 : 0;
+  d.layers_per_round = c->n_blocks * c->sel_layers;
+  p.fold = d.fold;
   hipError_t e;
 
   // ---- 1a. projections (only the reverse sweep and linear_down consume them) ---------------------------------

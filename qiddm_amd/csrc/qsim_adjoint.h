@@ -53,6 +53,8 @@ __device__ __forceinline__ void wave_reduce8_into(const T (&v)[8], int lane, int
   if (llane < 8) acc[(b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0)] += t;
 }
 
+constexpr int kFoldedAdjointMaxQubits = 8;
+
 struct AdjointScalars {
   int64_t gin_ld;   // row stride of grad_inputs
   int32_t want_inputs;
@@ -66,9 +68,179 @@ struct AdjointEngine {
   using C = V2<T>;
   static constexpr int LB = L::LB, R = L::R, LPS = L::LPS;
 
-  E fwd;    // gate table U
+  E fwd;    // gate table U (or, folded, the per-layer tables)
   E dag;    // same engine reading the dagger table U^dagger
-  T* kacc;  // this wave's K accumulators [n_rot][8] in LDS
+  T* kacc;  // this wave's K accumulators [n_rot][8] in LDS (folded: gradient sums [n_layers][2][kFoldSlots])
+
+  // ---- folded reverse sweep (CZ circuits, no RY data encoding) ----------------------------------------------
+  // The forward is  a <- D_l a ; a <- RY^l a  per layer (qsim_fused.h).  Walking back, with (psi, lambda) right after
+  // the layer's RYs:
+  //   d/dtheta_w = Re <lambda| (-iY_w) |psi>  = sum_pairs Re(conj(lambda_1) psi_0 - conj(lambda_0) psi_1)
+  //                (invariant under un-applying the other wires' RYs: taken wire by wire, then RY_w^dagger on both)
+  //   d/dalpha_w = Im <lambda| Z_w |psi>      = sum_k z_w(k) Im(conj(lambda_k) psi_k), right after D_l;
+  //                alpha^l_w = phi^l_w + omega^{l-1}_w (+ the data angle at a block start), so the SAME number is
+  //                d/dphi^l_w, d/domega^{l-1}_w and (times the encoding scale) a term of d/dx_w
+  // then D_l^* on both vectors.  Two 8-value wave reductions per layer instead of one per gate, no dagger table,
+  // no dRot contraction afterwards.  The diagonal dropped after the last RY layer has zero gradient.
+  static constexpr int kFoldSlots = N <= 8 ? 8 : 16;
+
+  template <int J>
+  __device__ __forceinline__ T ry_back_pairs(C (&psi)[R], C (&lam)[R], T c, T s) const {
+    T g = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if ((r & J) == 0) {
+        const C p0 = psi[r], p1 = psi[r | J], l0 = lam[r], l1 = lam[r | J];
+        g += (l1.x * p0.x + l1.y * p0.y) - (l0.x * p1.x + l0.y * p1.y);
+        // RY^dagger = [[c, s], [-s, c]]
+        psi[r] = __builtin_elementwise_fma(bcast<T>(s), p1, bcast<T>(c) * p0);
+        psi[r | J] = __builtin_elementwise_fma(bcast<T>(-s), p0, bcast<T>(c) * p1);
+        lam[r] = __builtin_elementwise_fma(bcast<T>(s), l1, bcast<T>(c) * l0);
+        lam[r | J] = __builtin_elementwise_fma(bcast<T>(-s), l0, bcast<T>(c) * l1);
+      }
+    }
+    return g;
+  }
+  template <int W>
+  __device__ __forceinline__ void ry_back_wires(C (&psi)[R], C (&lam)[R], const typename E::FoldedLayer& f,
+                                                T (&gth)[16]) const {
+    if constexpr (W < N) {
+      constexpr int Q = N - 1 - W;
+      const T c = f.ry[W].x, s = f.ry[W].y;
+      if constexpr (E::template kind_of<W>() == E::kReg) {
+        gth[W] = ry_back_pairs<(1 << (Q >= LB ? Q - LB : 0))>(psi, lam, c, s);
+      } else if constexpr (E::template kind_of<W>() == E::kSwap) {
+        fwd.template swap_reg0_with_lane_bit<Q>(psi);
+        fwd.template swap_reg0_with_lane_bit<Q>(lam);
+        // after the swap every lane holds complete pairs, but each pair is held by ONE of the two lanes that
+        // exchanged: the sum over lanes counts every pair once
+        gth[W] = ry_back_pairs<1>(psi, lam, c, s);
+        fwd.template swap_reg0_with_lane_bit<Q>(psi);
+        fwd.template swap_reg0_with_lane_bit<Q>(lam);
+      } else {
+        const bool hi = (fwd.llane >> Q) & 1;
+        const T sg = hi ? s : -s;  // the forward coefficient of the partner in this lane's row
+        T acc = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const C pp = xlane2<(1 << Q), T>(psi[r], fwd.lane);
+          const C lp = xlane2<(1 << Q), T>(lam[r], fwd.lane);
+          acc += lam[r].x * pp.x + lam[r].y * pp.y;  // Re(conj(lambda_own) psi_partner)
+          psi[r] = __builtin_elementwise_fma(bcast<T>(-sg), pp, bcast<T>(c) * psi[r]);
+          lam[r] = __builtin_elementwise_fma(bcast<T>(-sg), lp, bcast<T>(c) * lam[r]);
+        }
+        gth[W] = hi ? acc : -acc;
+      }
+      ry_back_wires<W + 1>(psi, lam, f, gth);
+    }
+  }
+
+  // state preparation + all layers of one round on the folded tables (fwd.s_gates -> the round's first layer)
+  template <typename Src>
+  __device__ __forceinline__ void forward_round_folded(const KScalars& p, const Src& amp_src, const T (&xs)[N],
+                                                       C (&psi)[R], C (&dx)[R], T (&cs)[N], T (&sn)[N], T& amp_inv,
+                                                       int n_layers_total) const {
+    const int lane = fwd.lane, sub = fwd.sub;
+    amp_inv = 1;
+    if (p.encoding == 1) {
+      T n2 = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int k = (r << LB) | sub;
+        T v = (T)p.pad_with;
+        if (k < p.n_features) v = amp_src(k) + (T)p.enc_offset;
+        psi[r] = C{v, (T)0};
+        n2 += v * v;
+      }
+      n2 = group_sum<T, LB>(n2, lane);
+      amp_inv = (T)1 / qsqrt(n2);
+#pragma unroll
+      for (int r = 0; r < R; ++r) psi[r] = C{psi[r].x * amp_inv, (T)0};
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) psi[r] = C{(T)0, (T)0};
+      psi[0] = C{sub == 0 ? (T)1 : (T)0, (T)0};
+    }
+    if (p.encoding == 2) {
+      fwd.half_angle_sincos(xs, cs, sn);
+      fwd.rz_diagonal(cs, sn, dx);
+    }
+    fwd.folded_round(p, psi, dx, 0, n_layers_total);
+  }
+
+  // gacc: this wave's [layers][2][kFoldSlots] accumulators of the round (theta block, then alpha block)
+  __device__ __forceinline__ void reverse_round_folded(const KScalars& p, C (&psi)[R], C (&lam)[R],
+                                                       const C (&dx)[R], T (&gx)[N], T* gacc) const {
+    const int layers = p.n_blocks * p.sel_layers;
+    const int llane = fwd.llane;
+#pragma unroll
+    for (int w = 0; w < N; ++w) gx[w] = 0;
+    for (int li = layers - 1; li >= 0; --li) {
+      const int s = li % p.sel_layers;
+      typename E::FoldedLayer f;
+      fwd.load_folded(li, (N > 1 && li > 0) ? ((li - 1) % p.sel_layers) % (N - 1) : -1, f);
+      T gth[16], gal[16];
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        gth[w] = 0;
+        gal[w] = 0;
+      }
+      ry_back_wires<0>(psi, lam, f, gth);
+      // d/dalpha_w right after the diagonal
+      T t[R], tsum = 0;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        t[r] = lam[r].x * psi[r].y - lam[r].y * psi[r].x;
+        tsum += t[r];
+      }
+#pragma unroll
+      for (int w = 0; w < N; ++w) {
+        const int q = N - 1 - w;
+        if (q >= LB) {
+          T acc = 0;
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc += ((r >> (q >= LB ? q - LB : 0)) & 1) ? -t[r] : t[r];
+          gal[w] = acc;
+        } else {
+          gal[w] = ((llane >> q) & 1) ? -tsum : tsum;
+        }
+      }
+      if (s == 0 && p.encoding == 2) {
+#pragma unroll
+        for (int w = 0; w < N; ++w) gx[w] += gal[w];  // the data angle sits in the same diagonal
+      }
+      {
+        T* dst = gacc + (size_t)li * 2 * kFoldSlots;
+        T v8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = gth[j];
+        wave_reduce8_into<T>(v8, fwd.lane, llane, dst);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v8[j] = gal[j];
+        wave_reduce8_into<T>(v8, fwd.lane, llane, dst + kFoldSlots);
+        if constexpr (N > 8) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v8[j] = gth[8 + j];
+          wave_reduce8_into<T>(v8, fwd.lane, llane, dst + 8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v8[j] = gal[8 + j];
+          wave_reduce8_into<T>(v8, fwd.lane, llane, dst + kFoldSlots + 8);
+        }
+      }
+      // D_l^* on both vectors
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        C ph = f.tlo;
+        if constexpr (R > 1) ph = cmul2<T>(f.thi[r], ph, times_i<T>(ph));
+        if (s == 0 && p.encoding == 2) ph = cmul2<T>(dx[r], ph, times_i<T>(ph));
+        const uint32_t sb = ((f.cz >> r) & 1u) << 31;
+        const C a = cmul2<T>(ph, psi[r], neg_i<T>(psi[r]));  // conj(ph) * psi
+        const C b = cmul2<T>(ph, lam[r], neg_i<T>(lam[r]));
+        psi[r] = C{flip_sign(a.x, sb), flip_sign(a.y, sb)};
+        lam[r] = C{flip_sign(b.x, sb), flip_sign(b.y, sb)};
+      }
+    }
+  }
 
   // K_{ab} += conj(lambda_a) psib_b for one in-register pair, then both vectors are un-applied
   template <int J>
@@ -319,12 +491,16 @@ struct AdjointEngine {
   // gin_row: where this sample's input gradient goes (may be null).
   template <typename Src>
   __device__ __forceinline__ void run(const KScalars& p, const Src& amp_src, T (&xs)[N],
-                                      const T* __restrict__ g_row, T* __restrict__ gin_row, bool valid) const {
+                                      const T* __restrict__ g_row, T* __restrict__ gin_row, bool valid,
+                                      bool folded = false) const {
     const int lane = fwd.lane, sub = fwd.sub;
     C psi[R], dx[R];
     T cs[N], sn[N];
     T amp_inv;
-    forward_round(p, amp_src, xs, psi, dx, cs, sn, amp_inv);
+    if (folded)
+      forward_round_folded(p, amp_src, xs, psi, dx, cs, sn, amp_inv, p.n_blocks * p.sel_layers);
+    else
+      forward_round(p, amp_src, xs, psi, dx, cs, sn, amp_inv);
     // ---- lambda = diag(g_eff) psi_final ----------------------------------------------------------------
     C lam[R];
     if (p.measure == 0) {
@@ -340,7 +516,10 @@ struct AdjointEngine {
       seed_expz(gw, psi, lam);
     }
     T gx[N];
-    reverse_round(p, psi, lam, dx, cs, sn, gx);
+    if (folded)
+      reverse_round_folded(p, psi, lam, dx, gx, kacc);
+    else
+      reverse_round(p, psi, lam, dx, cs, sn, gx);
     // ---- input gradients -----------------------------------------------------------------------------------------
     if (gin_row != nullptr) {
       if (p.encoding >= 2) {
@@ -392,19 +571,28 @@ __global__ __launch_bounds__(4 * kWave) void adjoint_kernel(const T* __restrict_
   unsigned char* extra = smem_raw + S::bytes(n_rot, p.imprimitive == 0, waves);
   T* dag_gates = reinterpret_cast<T*>(extra);
   T* kall = dag_gates + (size_t)n_rot * kLdsGateReals;
-  adj.fwd.fill_gates_from_table(table, n_rot, -1, 0);
-  for (int g = threadIdx.x; g < n_rot; g += blockDim.x) {
-    const T* u = table + (size_t)g * kVariants * kGateReals;
-    // U^dagger: (u00*, u10*; u01*, u11*)
-    E::put_gate(dag_gates + (size_t)g * kLdsGateReals, u[0], -u[1], u[4], -u[5], u[2], -u[3], u[6], -u[7]);
+  // CZ circuits: folded tables (appended to the gate table by qiddm_prepare_gates), per-layer gradient sums
+  // (n <= 8: with 8 or 16 amplitude pairs per lane the folded sweep spills -- measured 3.5x slower at n = 10)
+  const bool folded = p.fold != 0 && N >= 2 && N <= kFoldedAdjointMaxQubits;
+  const int n_layers = n_rot / N;
+  const int acc_len = folded ? n_layers * 2 * AdjointEngine<T, N>::kFoldSlots : n_rot * 8;
+  if (folded) {
+    adj.fwd.fill_folded_from_table(table + (size_t)n_rot * kVariants * kGateReals, n_layers);
+  } else {
+    adj.fwd.fill_gates_from_table(table, n_rot, -1, 0);
+    for (int g = threadIdx.x; g < n_rot; g += blockDim.x) {
+      const T* u = table + (size_t)g * kVariants * kGateReals;
+      // U^dagger: (u00*, u10*; u01*, u11*)
+      E::put_gate(dag_gates + (size_t)g * kLdsGateReals, u[0], -u[1], u[4], -u[5], u[2], -u[3], u[6], -u[7]);
+    }
   }
-  for (int i = threadIdx.x; i < waves * n_rot * 8; i += blockDim.x) kall[i] = 0;
+  for (int i = threadIdx.x; i < waves * acc_len; i += blockDim.x) kall[i] = 0;
   adj.fwd.fill_rings(p.imprimitive == 0);
   __syncthreads();
   adj.dag = adj.fwd;
   adj.dag.s_gates = dag_gates;
   const int wave = threadIdx.x >> 6;
-  adj.kacc = kall + (size_t)wave * n_rot * 8;
+  adj.kacc = kall + (size_t)wave * acc_len;
   const int sub = adj.fwd.sub;
   const int swave = adj.fwd.llane >> LB;
 
@@ -425,13 +613,13 @@ __global__ __launch_bounds__(4 * kWave) void adjoint_kernel(const T* __restrict_
     // gradient: it still takes part in the wave-wide exchanges but adds nothing to K
     const T* g_row = gout + sample * p.g_ld;
     T* gin_row = ad.want_inputs ? grad_inputs + sample * ad.gin_ld : nullptr;
-    adj.run(p, RowSrc<T>{inputs + sample * p.in_ld}, xs, g_row, gin_row, valid);
+    adj.run(p, RowSrc<T>{inputs + sample * p.in_ld}, xs, g_row, gin_row, valid, folded);
   }
   __syncthreads();
-  // block partial: sum the waves' accumulators in a fixed order (deterministic)
-  for (int i = threadIdx.x; i < n_rot * 8; i += blockDim.x) {
+  // block partial: sum the waves' accumulators in a fixed order (deterministic); slab stride n_rot * 8 either way
+  for (int i = threadIdx.x; i < acc_len; i += blockDim.x) {
     T tot = 0;
-    for (int w = 0; w < waves; ++w) tot += kall[(size_t)w * n_rot * 8 + i];
+    for (int w = 0; w < waves; ++w) tot += kall[(size_t)w * acc_len + i];
     k_partials[(size_t)blockIdx.x * n_rot * 8 + i] = tot;
   }
 }
@@ -489,6 +677,36 @@ __global__ __launch_bounds__(kWave) void adjoint_finalize_kernel(const T* __rest
   for (int i = 0; i < 8; ++i) k[i] = group_sum<double, 6>(k[i], lane);
   if (lane != 0) return;
   rot_grad_from_k(k, angles[g * 3 + 0], angles[g * 3 + 1], angles[g * 3 + 2], grad_angles + g * 3);
+}
+
+// folded slabs: [layer][2][slots] sums of d/dtheta and d/dalpha per wire; alpha^l = phi^l + omega^(l-1), so
+//   d/dphi^l = A[l],  d/dtheta^l = Th[l],  d/domega^l = A[l+1] inside the round (0 for a round's last layer)
+template <typename T>
+__global__ __launch_bounds__(kWave) void adjoint_finalize_folded_kernel(const T* __restrict__ partials,
+                                                                        int64_t n_partials, int64_t slab_stride,
+                                                                        int n, int layers_per_round, int slots,
+                                                                        int64_t n_rot, double* __restrict__ grad_angles) {
+  const int64_t g = blockIdx.x;
+  if (g >= n_rot) return;
+  const int lane = threadIdx.x;
+  const int layer = (int)(g / n), w = (int)(g - (int64_t)layer * n);
+  const bool has_next = (layer % layers_per_round) + 1 < layers_per_round;
+  double th = 0, al = 0, an = 0;
+#pragma unroll 4
+  for (int64_t pidx = lane; pidx < n_partials; pidx += kWave) {
+    const T* src = partials + pidx * slab_stride + (size_t)layer * 2 * slots;
+    th += (double)src[w];
+    al += (double)src[slots + w];
+    if (has_next) an += (double)src[2 * slots + slots + w];
+  }
+  th = group_sum<double, 6>(th, lane);
+  al = group_sum<double, 6>(al, lane);
+  an = group_sum<double, 6>(an, lane);
+  if (lane == 0) {
+    grad_angles[g * 3 + 0] = al;
+    grad_angles[g * 3 + 1] = th;
+    grad_angles[g * 3 + 2] = an;
+  }
 }
 
 }  // namespace qiddm

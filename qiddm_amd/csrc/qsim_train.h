@@ -29,9 +29,10 @@
 #include "qsim_adjoint.h"
 
 #ifndef QIDDM_TRAIN_OCC
-#define QIDDM_TRAIN_OCC 3  // waves per SIMD the reverse-sweep kernel is compiled for (register budget 512 / OCC);
-                           // measured at C2 (2560 rows): 1 -> 241 us, 2 -> 225, 3 -> 210 per step.  The forward-only
-                           // variant is fastest unconstrained (84 us vs 94-103)
+#define QIDDM_TRAIN_OCC 2  // waves per SIMD the reverse-sweep kernel is compiled for (register budget 512 / OCC).
+                           // Measured at C2 (2560 rows) per step: folded sweep 1 -> 185 us, 2 -> 167, 3 -> 222;
+                           // general sweep 1 -> 241, 2 -> 225, 3 -> 210.  The forward-only variant is fastest
+                           // unconstrained (84 us vs 94-103)
 #endif
 
 namespace qiddm {
@@ -40,6 +41,8 @@ struct TrainScalars {
   int64_t x_ld, noise_ld, rows;  // rows = B * T
   int32_t pixels, T, goal, train_quantum;
   int32_t samples_per_chunk, n_chunks, want_recon, want_elem;
+  int32_t fold, layers_per_round;  // fold: the reverse sweep runs on the folded tables (qsim_adjoint.h), slabs hold
+                                   // per-layer gradient sums instead of K
   double grad_scale;  // d(mean loss) / d(out) = grad_scale * residual
 };
 
@@ -169,25 +172,36 @@ __global__ __launch_bounds__(WPB* kWave, QUANTUM ? QIDDM_TRAIN_OCC : 1) void tra
     cur = reinterpret_cast<unsigned char*>(kall + (size_t)WPB * n_rot_all * 8);
   }
   T* hist_all = reinterpret_cast<T*>(cur);
-  adj.fwd.fill_gates_from_angles(angles, n_rot_all);
+  const bool folded = QUANTUM && d.fold != 0 && N >= 2 && N <= kFoldedAdjointMaxQubits;
+  const int layers = p.n_blocks * p.sel_layers;  // per round
+  using AE = AdjointEngine<T, N>;
+  const int acc_len = folded ? p.n_rounds * layers * 2 * AE::kFoldSlots : n_rot_all * 8;
+  if (folded)
+    adj.fwd.fill_folded_from_angles(angles, p.n_rounds * layers, layers);
+  else
+    adj.fwd.fill_gates_from_angles(angles, n_rot_all);
   adj.fwd.fill_rings(use_cnot);
   if constexpr (QUANTUM)
-    for (int i = threadIdx.x; i < WPB * n_rot_all * 8; i += blockDim.x) kall[i] = 0;
+    for (int i = threadIdx.x; i < WPB * acc_len; i += blockDim.x) kall[i] = 0;
   __syncthreads();
   if constexpr (QUANTUM) {
-    // U^dagger images from the forward ones: (u00*, u10*; u01*, u11*)
-    for (int g = threadIdx.x; g < n_rot_all; g += blockDim.x) {
-      const T* f = adj.fwd.s_gates_w + (size_t)g * kLdsGateReals;
-      E::put_gate(dag_gates + (size_t)g * kLdsGateReals, f[0], -f[1], f[12], -f[13], f[4], -f[5], f[8], -f[9]);
+    if (!folded) {
+      // U^dagger images from the forward ones: (u00*, u10*; u01*, u11*)
+      for (int g = threadIdx.x; g < n_rot_all; g += blockDim.x) {
+        const T* f = adj.fwd.s_gates_w + (size_t)g * kLdsGateReals;
+        E::put_gate(dag_gates + (size_t)g * kLdsGateReals, f[0], -f[1], f[12], -f[13], f[4], -f[5], f[8], -f[9]);
+      }
     }
     __syncthreads();
   }
+  const size_t round_gate_stride = folded ? (size_t)layers * Smem<T, N>::kFoldStride : (size_t)n_rot * kLdsGateReals;
+  const size_t round_acc_stride = folded ? (size_t)layers * 2 * AE::kFoldSlots : (size_t)n_rot * 8;
   adj.dag = adj.fwd;
   const T* fwd_base = adj.fwd.s_gates;
   const int lane = adj.fwd.lane, sub = adj.fwd.sub;
   const int wave = threadIdx.x >> 6;
   const int swave = adj.fwd.llane >> LB;
-  T* kacc_wave = kall + (size_t)wave * n_rot_all * 8;
+  T* kacc_wave = kall + (size_t)wave * acc_len;
   T* hist = hist_all + (size_t)(wave * SPW + swave) * p.n_rounds * N;
   const double* __restrict__ gram = proj + batch * (d.T + 1) * (2 * N) + N;  // row j' of G at gram[j'*2N + j]
   const double* __restrict__ cvec = gram + (size_t)N * (2 * N);
@@ -215,8 +229,11 @@ __global__ __launch_bounds__(WPB* kWave, QUANTUM ? QIDDM_TRAIN_OCC : 1) void tra
 #pragma unroll
         for (int j = 0; j < N; ++j) hist[round * N + j] = xs[j];
       }
-      adj.fwd.s_gates = fwd_base + (size_t)round * n_rot * kLdsGateReals;
-      adj.forward_round(p, NoSrc{}, xs, psi, dx, cs, sn, amp_inv);
+      adj.fwd.s_gates = fwd_base + (size_t)round * round_gate_stride;
+      if (folded)
+        adj.forward_round_folded(p, NoSrc{}, xs, psi, dx, cs, sn, amp_inv, layers);
+      else
+        adj.forward_round(p, NoSrc{}, xs, psi, dx, cs, sn, amp_inv);
       adj.measure_expz(psi, result);
       if (round + 1 < p.n_rounds) {
 #pragma unroll
@@ -242,18 +259,24 @@ __global__ __launch_bounds__(WPB* kWave, QUANTUM ? QIDDM_TRAIN_OCC : 1) void tra
       }
       // ---- reverse sweep, last round first; earlier rounds are re-run forward from their recorded inputs ----
       for (int round = p.n_rounds - 1; round >= 0; --round) {
-        adj.fwd.s_gates = fwd_base + (size_t)round * n_rot * kLdsGateReals;
+        adj.fwd.s_gates = fwd_base + (size_t)round * round_gate_stride;
         adj.dag.s_gates = dag_gates + (size_t)round * n_rot * kLdsGateReals;
-        adj.kacc = kacc_wave + (size_t)round * n_rot * 8;
+        adj.kacc = kacc_wave + (size_t)round * round_acc_stride;
         if (round != p.n_rounds - 1) {
 #pragma unroll
           for (int j = 0; j < N; ++j) xs[j] = hist[round * N + j];
-          adj.forward_round(p, NoSrc{}, xs, psi, dx, cs, sn, amp_inv);
+          if (folded)
+            adj.forward_round_folded(p, NoSrc{}, xs, psi, dx, cs, sn, amp_inv, layers);
+          else
+            adj.forward_round(p, NoSrc{}, xs, psi, dx, cs, sn, amp_inv);
         }
         C lam[R];
         adj.seed_expz(gw, psi, lam);
         T gx[N];
-        adj.reverse_round(p, psi, lam, dx, cs, sn, gx);
+        if (folded)
+          adj.reverse_round_folded(p, psi, lam, dx, gx, adj.kacc);
+        else
+          adj.reverse_round(p, psi, lam, dx, cs, sn, gx);
 #pragma unroll
         for (int j = 0; j < N; ++j) gw[j] = group_sum<T, LB>(gx[j], lane) * (T)p.enc_scale;
       }
@@ -265,9 +288,9 @@ __global__ __launch_bounds__(WPB* kWave, QUANTUM ? QIDDM_TRAIN_OCC : 1) void tra
   }
   if constexpr (QUANTUM) {
     __syncthreads();
-    for (int i = threadIdx.x; i < n_rot_all * 8; i += blockDim.x) {
+    for (int i = threadIdx.x; i < acc_len; i += blockDim.x) {  // slab stride n_rot_all * 8 either way
       T tot = 0;
-      for (int w = 0; w < WPB; ++w) tot += kall[(size_t)w * n_rot_all * 8 + i];
+      for (int w = 0; w < WPB; ++w) tot += kall[(size_t)w * acc_len + i];
       k_partials[(size_t)blockIdx.x * n_rot_all * 8 + i] = tot;
     }
   }
@@ -414,6 +437,29 @@ __global__ __launch_bounds__(kWave) void train_finalize_kernel(
   }
   const int64_t g = role - wblocks - 1 - n;
   if (g >= n_rot_all) return;
+  if (d.fold) {
+    // folded slabs: [layer][2][slots] sums of d/dtheta, d/dalpha per wire (adjoint_finalize_folded_kernel)
+    const int slots = n <= 8 ? 8 : 16;
+    const int layer = (int)(g / n), w = (int)(g - (int64_t)layer * n);
+    const bool has_next = (layer % d.layers_per_round) + 1 < d.layers_per_round;
+    double th = 0, al = 0, an = 0;
+#pragma unroll 4
+    for (int64_t pidx = lane; pidx < n_k_partials; pidx += kWave) {
+      const T* src = k_partials + pidx * n_rot_all * 8 + (size_t)layer * 2 * slots;
+      th += (double)src[w];
+      al += (double)src[slots + w];
+      if (has_next) an += (double)src[3 * slots + w];
+    }
+    th = group_sum<double, 6>(th, lane);
+    al = group_sum<double, 6>(al, lane);
+    an = group_sum<double, 6>(an, lane);
+    if (lane == 0) {
+      g_angles[g * 3 + 0] = al;
+      g_angles[g * 3 + 1] = th;
+      g_angles[g * 3 + 2] = an;
+    }
+    return;
+  }
   double k[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 4
   for (int64_t pidx = lane; pidx < n_k_partials; pidx += kWave) {
