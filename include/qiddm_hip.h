@@ -220,7 +220,13 @@ int qiddm_dense_sample(const qiddm_circuit_t *circ, const double *x, int64_t bat
                        int64_t in_features, const double *w_down, const double *b_down,
                        const double *angles, const double *w_up, const double *b_up,
                        int64_t out_features, int32_t post_mode, double noise_factor, int32_t n_steps,
-                       double *y, int64_t y_ld, int64_t y_step_stride, void *stream);
+                       double *y, int64_t y_ld, int64_t y_step_stride, const void *tables, void *stream);
+/* The sampler runs on per-layer tables derived from `angles` (RY coefficients, folded RZ/CZ phases).  With
+ * tables == NULL every launch rebuilds them in LDS; a caller that samples many times with the same weights
+ * builds them once: qiddm_dense_sample_prepare writes qiddm_dense_sample_tables_bytes(circ) bytes (circ->dtype)
+ * that stay valid until the angles change.                                                              */
+int64_t qiddm_dense_sample_tables_bytes(const qiddm_circuit_t *circ);
+int qiddm_dense_sample_prepare(const qiddm_circuit_t *circ, const double *angles, void *tables, void *stream);
 
 /* ---- fused quantum convolution -------------------------------------------------------
  * Replaces the (intended, SURVEY finding F3) forward of the reference's exported QConv2d

@@ -43,6 +43,8 @@ EXPORTS = (
     "qiddm_adjoint_finalize",
     "qiddm_dense_forward",
     "qiddm_dense_sample",
+    "qiddm_dense_sample_tables_bytes",
+    "qiddm_dense_sample_prepare",
     "qiddm_qconv_forward",
     "qiddm_train_workspace_bytes",
     "qiddm_train_step",
@@ -113,7 +115,11 @@ def _declare(lib):
                                         ctypes.c_double, vp, i64, vp]
     lib.qiddm_dense_sample.restype = ctypes.c_int
     lib.qiddm_dense_sample.argtypes = [P, vp, i64, i64, i64, vp, vp, vp, vp, vp, i64, ctypes.c_int32,
-                                       ctypes.c_double, ctypes.c_int32, vp, i64, i64, vp]
+                                       ctypes.c_double, ctypes.c_int32, vp, i64, i64, vp, vp]
+    lib.qiddm_dense_sample_tables_bytes.restype = i64
+    lib.qiddm_dense_sample_tables_bytes.argtypes = [P]
+    lib.qiddm_dense_sample_prepare.restype = ctypes.c_int
+    lib.qiddm_dense_sample_prepare.argtypes = [P, vp, vp, vp]
     lib.qiddm_adjoint_partials.restype = i64
     lib.qiddm_adjoint_partials.argtypes = [P, i64]
     lib.qiddm_backward_adjoint.restype = ctypes.c_int

@@ -234,8 +234,29 @@ def dense_forward(circ: Circuit, x: torch.Tensor, w_down, b_down, angles, w_up, 
     return y
 
 
+def dense_sample_tables(circ: Circuit, angles: torch.Tensor, precision: str | None = None) -> torch.Tensor:
+    """The sampler's per-layer tables for these weights (``qiddm_dense_sample_prepare``): build once, pass to
+    every ``dense_sample`` call until the angles change.  Raises ``QiddmError`` (-2) outside the sampler's range."""
+    precision = precision or _default_precision
+    _require_device(angles, "the circuit weights")
+    device = angles.device
+    ang = _as_f64(angles.detach(), device)
+    if tuple(ang.shape) != circ.angles_shape:
+        raise ValueError(f"angles must have shape {circ.angles_shape}; got {tuple(ang.shape)}")
+    lib = _capi.lib()
+    cs = circ.c_struct(precision)
+    need = lib.qiddm_dense_sample_tables_bytes(ctypes.byref(cs))
+    if need < 0:
+        _capi.check(int(need))
+    tables = torch.empty(need, dtype=torch.uint8, device=device)
+    _capi.check(lib.qiddm_dense_sample_prepare(ctypes.byref(cs), ang.data_ptr(), tables.data_ptr(),
+                                               _stream_ptr(device)))
+    return tables
+
+
 def dense_sample(circ: Circuit, x: torch.Tensor, w_down, b_down, angles, w_up, b_up, n_steps: int,
-                 precision: str | None = None, post_mode: int = 0, noise_factor: float = 1.0):
+                 precision: str | None = None, post_mode: int = 0, noise_factor: float = 1.0,
+                 tables: torch.Tensor | None = None):
     """``n_steps`` consecutive bodies of the sampling loop in ONE launch (``qiddm_dense_sample``).
     Returns (n_steps, batch, features) float64 -- the image after every step.  Raises ``QiddmError``
     (status -2) when the configuration is outside the fused sampler's range."""
@@ -253,7 +274,7 @@ def dense_sample(circ: Circuit, x: torch.Tensor, w_down, b_down, angles, w_up, b
         ctypes.byref(cs), xx.data_ptr(), xx.shape[0], xx.stride(0), xx.shape[1], wd.data_ptr(),
         0 if bd is None else bd.data_ptr(), ang.data_ptr(), wu.data_ptr(), 0 if bu is None else bu.data_ptr(),
         wu.shape[0], int(post_mode), float(noise_factor), int(n_steps), y.data_ptr(), y.stride(1),
-        y.stride(0), _stream_ptr(device)))
+        y.stride(0), 0 if tables is None else tables.data_ptr(), _stream_ptr(device)))
     return y
 
 

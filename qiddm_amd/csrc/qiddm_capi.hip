@@ -282,8 +282,8 @@ bool quad_supported(const qiddm_circuit_t* c, int64_t in_features, int64_t out_f
 
 template <typename T, int N>
 int launch_quad(const double* x, const double* wd, const double* bd, const double* angles, const double* wu,
-                const double* bu, double* y, const qiddm::QuadScalars& d, const qiddm::KScalars& p,
-                hipStream_t stream) {
+                const double* bu, double* y, const void* tables, const qiddm::QuadScalars& d,
+                const qiddm::KScalars& p, hipStream_t stream) {
   if (p.batch == 0 || d.n_steps == 0) return QIDDM_OK;
   const int64_t n_rot = (int64_t)p.n_rounds * p.n_blocks * p.sel_layers * N;
   const size_t smem = qiddm::QuadSmem<T, N>::bytes(n_rot);
@@ -301,21 +301,45 @@ int launch_quad(const double* x, const double* wd, const double* bd, const doubl
     big_lds_enabled[small] = true;
   }
   const unsigned blocks = (unsigned)(p.batch < 2048 ? p.batch : 2048);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, stream, x, wd, bd, angles, wu, bu, y, d, p);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, stream, x, wd, bd, angles, wu, bu, y,
+                     static_cast<const T*>(tables), d, p);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess)
     return fail(QIDDM_ERR_LAUNCH, "dense_quad_kernel<n=%d> launch failed: %s", N, hipGetErrorString(e));
   return QIDDM_OK;
 }
 
+template <typename T, int N>
+size_t quad_tables_bytes_n(int64_t n_rot) {
+  using QS = qiddm::QuadSmem<T, N>;
+  return (QS::ry_bytes(n_rot) + 15) / 16 * 16 + QS::tlo_bytes(n_rot) + QS::thi_bytes(n_rot);
+}
+template <typename T>
+size_t quad_tables_bytes(int n, int64_t n_rot) {
+  switch (n) {
+    case 8: return quad_tables_bytes_n<T, 8>(n_rot);
+    case 9: return quad_tables_bytes_n<T, 9>(n_rot);
+    default: return quad_tables_bytes_n<T, 10>(n_rot);
+  }
+}
+template <typename T, int N>
+int launch_quad_tables(const double* angles, void* tables, const qiddm::KScalars& p, int64_t n_rot, hipStream_t st) {
+  const size_t smem = (size_t)n_rot * sizeof(double);
+  if (smem > 48 * 1024) return fail(QIDDM_ERR_UNSUPPORTED, "too many Rot gates (%lld) for the table builder", (long long)n_rot);
+  hipLaunchKernelGGL((qiddm::quad_tables_kernel<T, N>), dim3(1), dim3(256), smem, st, angles, static_cast<T*>(tables), p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "quad_tables_kernel launch failed: %s", hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
 template <typename T>
 int dispatch_quad(int n, const double* x, const double* wd, const double* bd, const double* angles,
-                  const double* wu, const double* bu, double* y, const qiddm::QuadScalars& d,
+                  const double* wu, const double* bu, double* y, const void* tables, const qiddm::QuadScalars& d,
                   const qiddm::KScalars& p, hipStream_t st) {
   switch (n) {
-    case 8: return launch_quad<T, 8>(x, wd, bd, angles, wu, bu, y, d, p, st);
-    case 9: return launch_quad<T, 9>(x, wd, bd, angles, wu, bu, y, d, p, st);
-    case 10: return launch_quad<T, 10>(x, wd, bd, angles, wu, bu, y, d, p, st);
+    case 8: return launch_quad<T, 8>(x, wd, bd, angles, wu, bu, y, tables, d, p, st);
+    case 9: return launch_quad<T, 9>(x, wd, bd, angles, wu, bu, y, tables, d, p, st);
+    case 10: return launch_quad<T, 10>(x, wd, bd, angles, wu, bu, y, tables, d, p, st);
     default: return fail(QIDDM_ERR_UNSUPPORTED, "quad layout needs 8 <= n <= 10 (got %d)", n);
   }
 }
@@ -743,7 +767,7 @@ int qiddm_dense_forward(const qiddm_circuit_t* c, const double* x, int64_t batch
   static const bool no_quad = std::getenv("QIDDM_NO_QUAD") != nullptr;  // tuning switch
   if (!no_quad && batch <= 1024 && quad_supported(c, in_features, out_features))
     return qiddm_dense_sample(c, x, batch, x_ld, in_features, w_down, b_down, angles, w_up, b_up, out_features,
-                              post_mode, noise_factor, 1, y, y_ld, batch * y_ld, stream);
+                              post_mode, noise_factor, 1, y, y_ld, batch * y_ld, nullptr, stream);
   qiddm::KScalars p = make_params(c);
   p.batch = batch;
   qiddm::DenseScalars d;
@@ -809,7 +833,7 @@ int qiddm_dense_sample(const qiddm_circuit_t* c, const double* x, int64_t batch,
                        int64_t in_features, const double* w_down, const double* b_down,
                        const double* angles, const double* w_up, const double* b_up, int64_t out_features,
                        int32_t post_mode, double noise_factor, int32_t n_steps, double* y, int64_t y_ld,
-                       int64_t y_step_stride, void* stream) {
+                       int64_t y_step_stride, const void* tables, void* stream) {
   int rc = check_circuit(c);
   if (rc != QIDDM_OK) return rc;
   if (batch < 0 || n_steps < 0) return fail(QIDDM_ERR_INVALID, "negative batch / n_steps");
@@ -840,8 +864,34 @@ int qiddm_dense_sample(const qiddm_circuit_t* c, const double* x, int64_t batch,
   if (const char* e = std::getenv("QIDDM_STAMP_PTR")) d.stamps = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 0));
   hipStream_t st = static_cast<hipStream_t>(stream);
   return c->dtype == QIDDM_F32
-             ? dispatch_quad<float>(c->n_qubits, x, w_down, b_down, angles, w_up, b_up, y, d, p, st)
-             : dispatch_quad<double>(c->n_qubits, x, w_down, b_down, angles, w_up, b_up, y, d, p, st);
+             ? dispatch_quad<float>(c->n_qubits, x, w_down, b_down, angles, w_up, b_up, y, tables, d, p, st)
+             : dispatch_quad<double>(c->n_qubits, x, w_down, b_down, angles, w_up, b_up, y, tables, d, p, st);
+}
+
+int64_t qiddm_dense_sample_tables_bytes(const qiddm_circuit_t* c) {
+  if (check_circuit(c) != QIDDM_OK) return -1;
+  if (!quad_supported(c, 1, 1)) {
+    fail(QIDDM_ERR_UNSUPPORTED, "fused sampling loop: needs 8 <= n <= 10, CZ, RZ encoding, <Z>");
+    return QIDDM_ERR_UNSUPPORTED;
+  }
+  const int64_t n_rot = (int64_t)c->n_rounds * c->n_blocks * c->sel_layers * c->n_qubits;
+  return (int64_t)(c->dtype == QIDDM_F32 ? quad_tables_bytes<float>(c->n_qubits, n_rot)
+                                         : quad_tables_bytes<double>(c->n_qubits, n_rot));
+}
+
+int qiddm_dense_sample_prepare(const qiddm_circuit_t* c, const double* angles, void* tables, void* stream) {
+  const int64_t need = qiddm_dense_sample_tables_bytes(c);
+  if (need < 0) return (int)need;
+  if (!angles || !tables) return fail(QIDDM_ERR_INVALID, "angles/tables is NULL");
+  const qiddm::KScalars p = make_params(c);
+  const int64_t n_rot = (int64_t)c->n_rounds * c->n_blocks * c->sel_layers * c->n_qubits;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool f32 = c->dtype == QIDDM_F32;
+  switch (c->n_qubits) {
+    case 8: return f32 ? launch_quad_tables<float, 8>(angles, tables, p, n_rot, st) : launch_quad_tables<double, 8>(angles, tables, p, n_rot, st);
+    case 9: return f32 ? launch_quad_tables<float, 9>(angles, tables, p, n_rot, st) : launch_quad_tables<double, 9>(angles, tables, p, n_rot, st);
+    default: return f32 ? launch_quad_tables<float, 10>(angles, tables, p, n_rot, st) : launch_quad_tables<double, 10>(angles, tables, p, n_rot, st);
+  }
 }
 
 }  // extern "C"

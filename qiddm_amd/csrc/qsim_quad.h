@@ -94,11 +94,82 @@ struct QuadLayerData {
   }
 };
 
+// RY coefficients and phase tables of the quad layout from the raw angles (256 threads; `alpha` is LDS scratch of
+// n_rot doubles).  ry / tlo / thi may point to LDS (built per launch) or to global memory (built once per weights).
+template <typename T, int N>
+__device__ __forceinline__ void quad_build_tables(const double* __restrict__ angles, int n_rot, int layers_per_round,
+                                                  int sel_layers, V2<T>* ry, V2<T>* tlo, V2<T>* thi, double* alpha,
+                                                  int tid, uint32_t kbase) {
+  using C = V2<T>;
+  constexpr int R = 1 << (N - 8);
+  const int n_layers_all = n_rot / N;
+  for (int g = tid; g < n_rot; g += 256) {
+    double c, sn;
+    table_sincos<T>(0.5 * angles[g * 3 + 1], &sn, &c);
+    ry[g] = C{(T)c, (T)sn};
+    // the RZ(omega) of the layer before (same round) merges with this layer's RZ(phi)
+    const int li = (g / N) % layers_per_round;
+    alpha[g] = angles[g * 3 + 0] + (li > 0 ? angles[(g - N) * 3 + 2] : 0.0);
+  }
+  __syncthreads();
+  for (int l = 0; l < n_layers_all; ++l) {
+    const int li = l % layers_per_round;
+    // RZ(alpha) = diag(e^{-i alpha/2}, e^{+i alpha/2}): the phases of all wires add up to one angle
+    double ang = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const double al = alpha[l * N + (N - 1 - q)];
+      ang += ((kbase >> q) & 1u) ? 0.5 * al : -0.5 * al;
+    }
+    double c, sn;
+    table_sincos<T>(ang, &sn, &c);
+    if constexpr (R == 1) {
+      if (li > 0 && cz_ring_parity<N>(kbase, ((li - 1) % sel_layers) % (N - 1) + 1)) {
+        c = -c;
+        sn = -sn;
+      }
+    }
+    tlo[l * 256 + tid] = C{(T)c, (T)sn};
+  }
+  if constexpr (R > 1) {
+    for (int i = tid; i < n_layers_all * R; i += 256) {
+      const int l = i / R, r = i % R;
+      double ang = 0.0;
+#pragma unroll
+      for (int j = 0; j < N - 8; ++j) {
+        const double al = alpha[l * N + (N - 1 - (8 + j))];
+        ang += ((r >> j) & 1) ? 0.5 * al : -0.5 * al;
+      }
+      double c, sn;
+      table_sincos<T>(ang, &sn, &c);
+      thi[i] = C{(T)c, (T)sn};
+    }
+  }
+}
+
+// the tables as dense_quad_kernel lays them out in LDS ([ry | tlo | thi]), written once per weights
+template <typename T, int N>
+__global__ __launch_bounds__(256) void quad_tables_kernel(const double* __restrict__ angles, T* __restrict__ tables,
+                                                          const KScalars p) {
+  using C = V2<T>;
+  using QS = QuadSmem<T, N>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int n_rot = p.n_rounds * p.n_blocks * p.sel_layers * N;
+  const int tid = threadIdx.x;
+  const uint32_t kbase = ((uint32_t)(tid >> 6) << 6) | (uint32_t)logical_lane(tid & 63);
+  unsigned char* base = reinterpret_cast<unsigned char*>(tables);
+  C* ry = reinterpret_cast<C*>(base);
+  C* tlo = reinterpret_cast<C*>(base + (QS::ry_bytes(n_rot) + 15) / 16 * 16);
+  C* thi = reinterpret_cast<C*>(base + (QS::ry_bytes(n_rot) + 15) / 16 * 16 + QS::tlo_bytes(n_rot));
+  quad_build_tables<T, N>(angles, n_rot, p.n_blocks * p.sel_layers, p.sel_layers, ry, tlo, thi,
+                          reinterpret_cast<double*>(smem_raw), tid, kbase);
+}
+
 template <typename T, int N, int PPT>
 __global__ __launch_bounds__(256) void dense_quad_kernel(
     const double* __restrict__ x, const double* __restrict__ wd, const double* __restrict__ bd,
     const double* __restrict__ angles, const double* __restrict__ wu, const double* __restrict__ bu,
-    double* __restrict__ y, const QuadScalars d, const KScalars p) {
+    double* __restrict__ y, const T* __restrict__ tables, const QuadScalars d, const KScalars p) {
   static_assert(N >= 8 && N <= 10, "quad layout: 8..10 qubits");
   using E = Engine<T, N - 2>;  // lane bits 0..5 + register bits; its register bit j is index bit 8 + j
   using C = V2<T>;
@@ -147,50 +218,18 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
     }
   }
 
-  // ---- staging: RY coefficients, phase tables, CZ parity bits ----------------------------------------------
+  // ---- staging: RY coefficients and phase tables (built here, or copied when the caller prepared them once per
+  //      weights with quad_tables_kernel), CZ parity bits ------------------------------------------------------
   const int layers_per_round = p.n_blocks * p.sel_layers;
   const uint32_t kbase = ((uint32_t)wv << 6) | (uint32_t)llane;  // index bits 0..7 of this thread
-  for (int g = tid; g < n_rot; g += 256) {
-    double c, sn;
-    table_sincos<T>(0.5 * angles[g * 3 + 1], &sn, &c);
-    s_ry[g] = C{(T)c, (T)sn};
-    // the RZ(omega) of the layer before (same round) merges with this layer's RZ(phi)
-    const int li = (g / N) % layers_per_round;
-    s_alpha[g] = angles[g * 3 + 0] + (li > 0 ? angles[(g - N) * 3 + 2] : 0.0);
-  }
-  __syncthreads();
-  for (int l = 0; l < n_layers_all; ++l) {
-    const int li = l % layers_per_round;
-    // RZ(alpha) = diag(e^{-i alpha/2}, e^{+i alpha/2}): the phases of all wires add up to one angle
-    double ang = 0.0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const double al = s_alpha[l * N + (N - 1 - q)];
-      ang += ((kbase >> q) & 1u) ? 0.5 * al : -0.5 * al;
-    }
-    double c, sn;
-    table_sincos<T>(ang, &sn, &c);
-    if constexpr (R == 1) {
-      if (li > 0 && cz_ring_parity<N>(kbase, ((li - 1) % p.sel_layers) % (N - 1) + 1)) {
-        c = -c;
-        sn = -sn;
-      }
-    }
-    s_tlo[l * 256 + tid] = C{(T)c, (T)sn};
+  if (tables != nullptr) {
+    const int n_t = (int)((QS::ry_bytes(n_rot) + 15) / 16 * 16 + QS::tlo_bytes(n_rot) + QS::thi_bytes(n_rot)) / (int)sizeof(T);
+    T* dst = reinterpret_cast<T*>(s_ry);
+    for (int i = tid; i < n_t; i += 256) dst[i] = tables[i];
+  } else {
+    quad_build_tables<T, N>(angles, n_rot, layers_per_round, p.sel_layers, s_ry, s_tlo, s_thi, s_alpha, tid, kbase);
   }
   if constexpr (R > 1) {
-    for (int i = tid; i < n_layers_all * R; i += 256) {
-      const int l = i / R, r = i % R;
-      double ang = 0.0;
-#pragma unroll
-      for (int j = 0; j < N - 8; ++j) {
-        const double al = s_alpha[l * N + (N - 1 - (8 + j))];
-        ang += ((r >> j) & 1) ? 0.5 * al : -0.5 * al;
-      }
-      double c, sn;
-      table_sincos<T>(ang, &sn, &c);
-      s_thi[i] = C{(T)c, (T)sn};
-    }
     for (int rr = 1; rr < N; ++rr) {
       uint32_t bits = 0;
 #pragma unroll

@@ -75,6 +75,15 @@ class _QuantumNet(nn.Module):
         return (not torch.is_grad_enabled()) and self.qnode is self._own_qnode and \
             getattr(self, "add_noise", 0) in self._fusable_noise
 
+    def _sampler_tables(self, circ, angles):
+        """Per-layer tables of the fused sampler, rebuilt only when the weights (or the precision) changed."""
+        stamp = (angles._version, angles.data_ptr(), str(angles.device), _c._default_precision, circ.angles_shape)
+        cached = getattr(self, "_sampler_tables_cache", None)
+        if cached is None or cached[0] != stamp:
+            cached = (stamp, _c.dense_sample_tables(circ, angles.reshape(circ.angles_shape)))
+            self._sampler_tables_cache = cached
+        return cached[1]
+
     # -- fused training step (SURVEY.md section 8f rank 1) -------------------------------------------------
     def _train_family(self):
         """``(circuit, linear_down, angles parameter, linear_up)`` for nets of the
@@ -292,7 +301,7 @@ class QNN_noise(_QuantumNet):
             out = _c.dense_sample(circ, flat, self.linear_down.weight, self.linear_down.bias,
                                   self.weights.reshape(circ.angles_shape), self.linear_up.weight,
                                   self.linear_up.bias, n_steps, post_mode=0 if goal == "data" else 1,
-                                  noise_factor=noise_factor)
+                                  noise_factor=noise_factor, tables=self._sampler_tables(circ, self.weights))
         except _capi.QiddmError as e:
             if e.code == -2:      # outside the fused sampler's range (e.g. tables beyond LDS): step by step
                 return None
@@ -498,7 +507,8 @@ class _QIDDMBase(_QuantumNet):
         try:
             out = _c.dense_sample(circ, flat, self.linear_down.weight, self.linear_down.bias, self.weights1,
                                   self.linear_up.weight, self.linear_up.bias, n_steps,
-                                  post_mode=0 if goal == "data" else 1, noise_factor=noise_factor)
+                                  post_mode=0 if goal == "data" else 1, noise_factor=noise_factor,
+                                  tables=self._sampler_tables(circ, self.weights1))
         except _capi.QiddmError as e:
             if e.code == -2:      # outside the fused sampler's range: step by step
                 return None
