@@ -83,7 +83,9 @@ __global__ __launch_bounds__(4 * kWave) void train_project_kernel(
   const int groups_per_sample = (d.T + 1 + LG - 1) / LG;
   const int64_t unit = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int64_t n_blend = batch * groups_per_sample;
-  if (unit >= n_blend + N + 2) return;
+  // (as written, finding F1, nothing downstream reads the W_up projections: only W_down x is taken)
+  const bool quantum = d.train_quantum != 0;
+  if (unit >= n_blend + (quantum ? N + 2 : 0)) return;
   const int kind = unit < n_blend ? 0 : (int)(unit - n_blend) + 1;  // 0 blend, 1..N W_up column, N+1 b_up, N+2 ones
   const int64_t b = kind == 0 ? unit / groups_per_sample : 0;
   const int t0 = kind == 0 ? (int)(unit - b * groups_per_sample) * LG : 0;
@@ -95,12 +97,14 @@ __global__ __launch_bounds__(4 * kWave) void train_project_kernel(
   for (int l = 0; l < LG; ++l)
 #pragma unroll
     for (int j = 0; j < 2 * N; ++j) acc[l][j] = 0.0;
+  // one wavefront per SIMD at the benchmark shapes: keep several iterations' loads in flight
+#pragma unroll 4
   for (int pix = lane; pix < P; pix += kWave) {
     double wdv[N], wuv[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
       wdv[j] = wd[(size_t)j * P + pix];
-      wuv[j] = wu[(size_t)pix * N + j];
+      wuv[j] = quantum ? wu[(size_t)pix * N + j] : 0.0;
     }
     if (kind == 0) {
       const double xv = x[b * d.x_ld + pix];
@@ -109,9 +113,10 @@ __global__ __launch_bounds__(4 * kWave) void train_project_kernel(
       for (int l = 0; l < LG; ++l) {
         const double v = blend_noise(xv, nz, w[l]);
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-          acc[l][j] = fma(v, wdv[j], acc[l][j]);
-          acc[l][N + j] = fma(v, wuv[j], acc[l][N + j]);
+        for (int j = 0; j < N; ++j) acc[l][j] = fma(v, wdv[j], acc[l][j]);
+        if (quantum) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) acc[l][N + j] = fma(v, wuv[j], acc[l][N + j]);
         }
       }
     } else {
