@@ -510,19 +510,6 @@ def run_shift_sweep(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch
     return grad_angles, grad_inputs
 
 
-def _rot_matrices(angles: torch.Tensor) -> torch.Tensor:
-    """(G, 3) float64 (phi, theta, omega) -> (G, 2, 2) complex128 RZ(omega) RY(theta) RZ(phi),
-    differentiable (used to contract the adjoint kernel's K matrices with dRot/dangle)."""
-    phi, theta, omega = angles[:, 0], angles[:, 1], angles[:, 2]
-    c, s = torch.cos(0.5 * theta), torch.sin(0.5 * theta)
-    a, b = 0.5 * (phi + omega), 0.5 * (phi - omega)
-    ea = torch.complex(torch.cos(a), torch.sin(a))
-    eb = torch.complex(torch.cos(b), torch.sin(b))
-    row0 = torch.stack([ea.conj() * c, -eb * s], dim=-1)
-    row1 = torch.stack([eb.conj() * s, ea * c], dim=-1)
-    return torch.stack([row0, row1], dim=-2)
-
-
 def run_adjoint(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch.Tensor,
                 precision: str | None = None, with_inputs: bool = True):
     """Reverse-mode gradients of one QNode round (``qiddm_backward_adjoint``).

@@ -3,9 +3,10 @@
 // At BASELINE config 2 (batch 256, n = 8) the one-wave-per-sample kernels leave three of every four
 // SIMDs idle and the step is pure latency (phase stamps).  Here one 256-thread
 // workgroup owns a sample: amplitude index k = (r << 8) | (wave << 6) | lane, i.e. index bits 6 and 7
-// live in the wave number.  Gates on lane / register bits reuse the Engine primitives (packed FMA, DPP,
-// permlane swaps); the two wave-bit gates of a layer are applied TOGETHER as one 4x4 exchange through
-// a double-buffered LDS slab (one s_barrier per layer).  linear_down / linear_up are split over all 256
+// live in the wave number.  The circuit runs on folded per-layer tables (below): one phase multiply per amplitude,
+// then real RY gates -- lane bits fetch their partner with a DPP / permlane move (xlane2), register bits pair in
+// registers, and the two wave-bit gates of a layer are applied TOGETHER as one real 4x4 exchange through a
+// double-buffered LDS slab (one s_barrier per layer).  linear_down / linear_up are split over all 256
 // threads, and the whole sampling loop x <- net(x) (reference src/models.py:124-136) can run for
 // `n_steps` iterations inside the launch with x held in registers.
 //
@@ -171,7 +172,6 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
     const double* __restrict__ angles, const double* __restrict__ wu, const double* __restrict__ bu,
     double* __restrict__ y, const T* __restrict__ tables, const QuadScalars d, const KScalars p) {
   static_assert(N >= 8 && N <= 10, "quad layout: 8..10 qubits");
-  using E = Engine<T, N - 2>;  // lane bits 0..5 + register bits; its register bit j is index bit 8 + j
   using C = V2<T>;
   constexpr int R = 1 << (N - 8);
   // PPT pixels per thread (in/out features <= 256 * PPT) stay in registers across the steps
