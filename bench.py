@@ -338,6 +338,16 @@ def main():
                          "steps_per_launch": spl,
                          "kernel_avg_us": kern_us,
                          "algorithmic_bytes_per_launch": alg_bytes,
+                         # what the kernel actually executes (folded tables): per amplitude and layer one complex
+                         # multiply (6 flop) + n real RY updates (6 flop each), plus <Z> and the two linears
+                         "valu": (lambda fl: {"executed_flop_per_sample_step": fl,
+                                              "achieved": fl * args.batch * spl / (kern_us * 1e-6) / 1e12,
+                                              "peak": 157.3, "unit": "TFLOP/s",
+                                              "frac": fl * args.batch * spl / (kern_us * 1e-6) / 1e12 / 157.3,
+                                              "note": "latency-bound at batch 256: one sample per CU, one wavefront "
+                                                      "per SIMD, every layer a dependent chain"})(
+                             QDEPTH * (1 << N_QUBITS) * (6 + 6 * N_QUBITS) + 2 * N_QUBITS * (1 << N_QUBITS)
+                             + 2 * 2 * IMG * IMG * N_QUBITS),
                          "note": "algorithmic = (G+1/2)*16*2^n B per sample (SURVEY 8d) x batch x steps per "
                                  "launch; the slab lives in registers (4 wavefronts per sample), so physical "
                                  "HBM traffic is the first image in + one image out per step; the kernel also "
