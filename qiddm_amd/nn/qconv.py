@@ -64,7 +64,7 @@ class QConv2d(torch.nn.Module):
         w_out = w_in + 2 * self.padding[1] - self.kernel_size[1] + 1
         if (not torch.is_grad_enabled() and self.qnode is self._own_qnode and self.wires <= 10
                 and 2 * self.out_channels <= 2 ** self.wires):
-            if not self.training and x.is_cuda:
+            if not self.training and x.is_cuda and _c._default_precision == "f32":
                 # eval mode (reference :92-126): the cached circuit unitary, then one GEMM on the matrix cores
                 return _c.qconv_unitary_forward(x, self._eval_unitary(), self.wires, self.out_channels,
                                                 self.kernel_size, self.padding)
@@ -83,6 +83,8 @@ class QConv2d(torch.nn.Module):
         if torch.is_grad_enabled() or self.training or self.qnode is not self._own_qnode or not x.is_cuda \
                 or self.wires > 10 or 2 * self.out_channels > 2 ** self.wires or x.shape[1] != self.in_channels:
             return None
+        if _c._default_precision != "f32":
+            return None      # the GEMM multiplies in float32; the float64 setting keeps the float64 circuit kernel
         if batch_norm is not None and (batch_norm.training or batch_norm.running_mean is None
                                        or batch_norm.num_features != self.out_channels):
             return None

@@ -160,3 +160,22 @@ def test_unet_simple_fused_inference_vs_module_by_module():
             xx = blk.net(torch.cat([up, skip], dim=1))
         want = net.final_conv(xx)
     assert torch.allclose(got, want, atol=5e-6, rtol=1e-6)
+
+
+def test_float64_setting_keeps_the_float64_circuit_kernel():
+    from oracle import circuits as oc
+    from qiddm_amd import circuit as qc
+    from qiddm_amd import nn
+    torch.manual_seed(9)
+    layer = nn.QConv2d(2, 4, qdepth=2).to(DEV).eval()
+    x = torch.rand(1, 2, 5, 5, dtype=torch.float64, device=DEV)
+    want = oc.qconv2d_forward(x.cpu(), layer.weights.detach().cpu(), 4, (3, 3), (1, 1))
+    prev = qc._default_precision
+    qc.set_default_precision("f64")
+    try:
+        with torch.no_grad():
+            got = layer(x).cpu()
+        assert layer.eval_forward(x) is None
+    finally:
+        qc.set_default_precision(prev)
+    assert (got - want).abs().max().item() < 1e-11
