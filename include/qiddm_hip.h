@@ -171,7 +171,7 @@ int qiddm_forward_shifted(const qiddm_circuit_t *circ, const void *inputs, int64
  *                order K00 K01 K10 K11); the caller sums them over dim 0 and contracts with the analytic
  *                dRot/d(phi,theta,omega):  dL/dangle = 2 Re sum_ab (dU/dangle)_ab K_ab.
  *                n_partials = qiddm_adjoint_partials(circ, batch).  For CZ circuits without RY data encoding and
- *                n <= 8 the slabs (same size) hold per-layer sums of d/dtheta and d/d(phi^l + omega^(l-1)) instead
+ *                n <= 9 the slabs (same size) hold per-layer sums of d/dtheta and d/d(phi^l + omega^(l-1)) instead
  *                (folded reverse sweep): treat them as opaque and hand them to qiddm_adjoint_finalize.
  *   grad_inputs: (batch, gin_ld) dL/d(inputs): n columns for RZ / RY encodings, n_features columns for
  *                the amplitude embedding (gradient through pad + normalise); may be NULL.

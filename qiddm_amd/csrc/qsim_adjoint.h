@@ -53,7 +53,7 @@ __device__ __forceinline__ void wave_reduce8_into(const T (&v)[8], int lane, int
   if (llane < 8) acc[(b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0)] += t;
 }
 
-constexpr int kFoldedAdjointMaxQubits = 8;
+constexpr int kFoldedAdjointMaxQubits = 9;
 
 struct AdjointScalars {
   int64_t gin_ld;   // row stride of grad_inputs
@@ -169,8 +169,10 @@ struct AdjointEngine {
   }
 
   // gacc: this wave's [layers][2][kFoldSlots] accumulators of the round (theta block, then alpha block)
+  // (register diet for R >= 8: the register-bit phases are read from LDS where they are used and the data diagonal
+  //  is rebuilt from (cs, sn) at the block starts instead of staying live through the whole sweep)
   __device__ __forceinline__ void reverse_round_folded(const KScalars& p, C (&psi)[R], C (&lam)[R],
-                                                       const C (&dx)[R], T (&gx)[N], T* gacc) const {
+                                                       const T (&cs)[N], const T (&sn)[N], T (&gx)[N], T* gacc) const {
     const int layers = p.n_blocks * p.sel_layers;
     const int llane = fwd.llane;
 #pragma unroll
@@ -178,7 +180,7 @@ struct AdjointEngine {
     for (int li = layers - 1; li >= 0; --li) {
       const int s = li % p.sel_layers;
       typename E::FoldedLayer f;
-      fwd.load_folded(li, (N > 1 && li > 0) ? ((li - 1) % p.sel_layers) % (N - 1) : -1, f);
+      fwd.load_folded_light(li, (N > 1 && li > 0) ? ((li - 1) % p.sel_layers) % (N - 1) : -1, f);
       T gth[16], gal[16];
 #pragma unroll
       for (int w = 0; w < 16; ++w) {
@@ -228,11 +230,24 @@ struct AdjointEngine {
         }
       }
       // D_l^* on both vectors
+      const bool upload = s == 0 && p.encoding == 2;
+      if (upload) {
+        C dxl[R];
+        fwd.rz_diagonal(cs, sn, dxl);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          psi[r] = cmul2<T>(dxl[r], psi[r], neg_i<T>(psi[r]));
+          lam[r] = cmul2<T>(dxl[r], lam[r], neg_i<T>(lam[r]));
+        }
+      }
+      const C* thi_p = reinterpret_cast<const C*>(fwd.s_gates + (size_t)li * E::S::kFoldStride) + N + LPS;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         C ph = f.tlo;
-        if constexpr (R > 1) ph = cmul2<T>(f.thi[r], ph, times_i<T>(ph));
-        if (s == 0 && p.encoding == 2) ph = cmul2<T>(dx[r], ph, times_i<T>(ph));
+        if constexpr (R > 1) {
+          const C th = thi_p[r];
+          ph = cmul2<T>(th, ph, times_i<T>(ph));
+        }
         const uint32_t sb = ((f.cz >> r) & 1u) << 31;
         const C a = cmul2<T>(ph, psi[r], neg_i<T>(psi[r]));  // conj(ph) * psi
         const C b = cmul2<T>(ph, lam[r], neg_i<T>(lam[r]));
@@ -517,7 +532,7 @@ struct AdjointEngine {
     }
     T gx[N];
     if (folded)
-      reverse_round_folded(p, psi, lam, dx, gx, kacc);
+      reverse_round_folded(p, psi, lam, cs, sn, gx, kacc);
     else
       reverse_round(p, psi, lam, dx, cs, sn, gx);
     // ---- input gradients -----------------------------------------------------------------------------------------
@@ -572,7 +587,7 @@ __global__ __launch_bounds__(4 * kWave) void adjoint_kernel(const T* __restrict_
   T* dag_gates = reinterpret_cast<T*>(extra);
   T* kall = dag_gates + (size_t)n_rot * kLdsGateReals;
   // CZ circuits: folded tables (appended to the gate table by qiddm_prepare_gates), per-layer gradient sums
-  // (n <= 8: with 8 or 16 amplitude pairs per lane the folded sweep spills -- measured 3.5x slower at n = 10)
+  // (n <= 9: with 16 amplitudes per lane the folded sweep spills -- measured 3x slower at n = 10)
   const bool folded = p.fold != 0 && N >= 2 && N <= kFoldedAdjointMaxQubits;
   const int n_layers = n_rot / N;
   const int acc_len = folded ? n_layers * 2 * AdjointEngine<T, N>::kFoldSlots : n_rot * 8;

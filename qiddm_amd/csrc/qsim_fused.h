@@ -401,6 +401,13 @@ struct Engine {
     }
     f.cz = (N > 1 && prev_range_index >= 0) ? s_cz[prev_range_index * kWave + llane] : 0u;
   }
+  __device__ __forceinline__ void load_folded_light(int layer, int prev_range_index, FoldedLayer& f) const {
+    const C* base = reinterpret_cast<const C*>(s_gates + (size_t)layer * S::kFoldStride);
+#pragma unroll
+    for (int w = 0; w < N; ++w) f.ry[w] = base[w];
+    f.tlo = base[N + sub];
+    f.cz = (N > 1 && prev_range_index >= 0) ? s_cz[prev_range_index * kWave + llane] : 0u;
+  }
   // RY(theta) on wire W with the coefficients (c, s): register pairs, swap trick or lane partner
   template <int W>
   __device__ __forceinline__ void ry_wires(C (&a)[R], const FoldedLayer& f) const {

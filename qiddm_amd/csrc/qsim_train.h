@@ -279,7 +279,7 @@ __global__ __launch_bounds__(WPB* kWave, QUANTUM ? QIDDM_TRAIN_OCC : 1) void tra
         adj.seed_expz(gw, psi, lam);
         T gx[N];
         if (folded)
-          adj.reverse_round_folded(p, psi, lam, dx, gx, adj.kacc);
+          adj.reverse_round_folded(p, psi, lam, cs, sn, gx, adj.kacc);
         else
           adj.reverse_round(p, psi, lam, dx, cs, sn, gx);
 #pragma unroll
