@@ -221,10 +221,10 @@ def secondary_measurements(dev, batch):
             t = _time_fn(step, 10 if tag != "parameter_shift" else 2, warm=1)
             out[f"train_images_per_s_{tag}"] = xt.shape[0] * tau / t
             if tag != "parameter_shift":
-                # the same step (fused qiddm_train_step + one-launch Adam) recorded into a HIP graph, noise drawn on device
+                # the same step (fused qiddm_train_step + one-launch Adam) recorded into a HIP graph, noise generated in the launch
                 from qiddm_amd.optim import FusedAdam
                 from qiddm_amd.trainer import GraphedTrainStep
-                gstep = GraphedTrainStep(diff, FusedAdam(diff.parameters(), lr=1e-3), xt, T=tau, noise="device")
+                gstep = GraphedTrainStep(diff, FusedAdam(diff.parameters(), lr=1e-3), xt, T=tau, noise="fused")
                 t = _time_fn(lambda: gstep(xt), 50, warm=3)
                 out[f"train_images_per_s_{tag}_graphed"] = xt.shape[0] * tau / t
         except Exception as e:  # pragma: no cover

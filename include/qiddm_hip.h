@@ -265,7 +265,8 @@ int qiddm_qconv_forward(const qiddm_circuit_t *circ, const double *x, int64_t ba
  * All sums have a fixed order: bit-reproducible.  Three launches on `stream`, no host synchronisation. */
 typedef struct qiddm_train_args {
   const double *x;        /* (batch, pixels) float64, row stride x_ld                      */
-  const float *noise;     /* (batch, pixels) float32, row stride noise_ld                  */
+  float *noise;           /* (batch, pixels) float32, row stride noise_ld: the N(0.5, 0.2) field -- read,
+                           * or, when rng_state != NULL, generated in the launch and written here        */
   const float *schedule;  /* (tau + 1)                                                     */
   int64_t x_ld, noise_ld, batch;
   int32_t pixels, tau, goal, train_quantum;
@@ -275,6 +276,8 @@ typedef struct qiddm_train_args {
   double *loss;                    /* (1)                                                   */
   double *g_w_down, *g_b_down, *g_angles, *g_w_up, *g_b_up;
   double *recon, *elem_loss;       /* optional                                              */
+  uint64_t *rng_state;             /* optional: device {seed, offset}; Philox4x32-10 + Box-Muller per element,
+                                    * offset advanced by one per call (graph-replayable)                 */
 } qiddm_train_args_t;
 
 /* bytes of scratch qiddm_train_step needs (negative: error code) */

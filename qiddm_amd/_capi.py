@@ -165,7 +165,7 @@ class TrainArgs(ctypes.Structure):
         ("loss", ctypes.c_void_p),
         ("g_w_down", ctypes.c_void_p), ("g_b_down", ctypes.c_void_p), ("g_angles", ctypes.c_void_p),
         ("g_w_up", ctypes.c_void_p), ("g_b_up", ctypes.c_void_p),
-        ("recon", ctypes.c_void_p), ("elem_loss", ctypes.c_void_p),
+        ("recon", ctypes.c_void_p), ("elem_loss", ctypes.c_void_p), ("rng_state", ctypes.c_void_p),
     ]
 
 

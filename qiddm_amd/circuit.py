@@ -376,12 +376,14 @@ _train_workspaces = {}
 
 def train_step(circ: Circuit, x: torch.Tensor, noise: torch.Tensor, schedule: torch.Tensor, goal: str,
                w_down, b_down, angles, w_up, b_up, train_quantum: bool, want_recon: bool = False,
-               want_elem_loss: bool = False, precision: str | None = None):
+               want_elem_loss: bool = False, precision: str | None = None, rng_state: torch.Tensor | None = None):
     """One fused training step of the denoise loop (``qiddm_train_step``): noising, net forward, MSE and the
     backward pass of ``Diffusion.run_training_step_data/_noise`` (reference src/models.py:44-104) for a
     linear_down -> circuit -> linear_up net, in three launches and without a (batch*tau, pixels) tensor.
 
     x (B, P) float64; noise (B, P) float32; schedule (tau+1,) float32 with schedule[0] == 0.
+    ``rng_state`` (2,) int64 on the device = {seed, offset}: the noise field is then generated inside the launch
+    (Philox) and WRITTEN to ``noise``, and the offset is advanced -- no separate RNG launches.
     Returns a dict: ``loss`` (0-d), ``w_up``, ``b_up`` and -- when ``train_quantum`` -- ``w_down``, ``b_down``,
     ``angles`` gradients (float64, parameter-shaped), plus ``recon`` / ``elem_loss`` (B*tau, P) on request."""
     precision = precision or _default_precision
@@ -394,6 +396,11 @@ def train_step(circ: Circuit, x: torch.Tensor, noise: torch.Tensor, schedule: to
     nz = noise.to(device=device, dtype=torch.float32)
     if nz.stride(-1) != 1:
         nz = nz.contiguous()
+    if rng_state is not None:
+        if nz.data_ptr() != noise.data_ptr():
+            raise ValueError("with rng_state the noise buffer is an output: pass a float32 device tensor")
+        if rng_state.dtype != torch.int64 or rng_state.numel() != 2 or not rng_state.is_cuda:
+            raise ValueError("rng_state must be a (2,) int64 device tensor {seed, offset}")
     sch = schedule.to(device=device, dtype=torch.float32).reshape(-1).contiguous()
     wd, bd, wu, bu, ang = (_as_f64(t, device) for t in (w_down, b_down, w_up, b_up, angles))
     if tuple(ang.shape) != circ.angles_shape:
@@ -432,7 +439,7 @@ def train_step(circ: Circuit, x: torch.Tensor, noise: torch.Tensor, schedule: to
         w_down=ptr(wd), b_down=ptr(bd), angles=ptr(ang), w_up=ptr(wu), b_up=ptr(bu), loss=ptr(out["loss"]),
         g_w_down=ptr(out.get("w_down")), g_b_down=ptr(out.get("b_down")), g_angles=ptr(out.get("angles")),
         g_w_up=ptr(out["w_up"]), g_b_up=ptr(out["b_up"]), recon=ptr(out.get("recon")),
-        elem_loss=ptr(out.get("elem_loss")))
+        elem_loss=ptr(out.get("elem_loss")), rng_state=ptr(rng_state))
     _capi.check(lib.qiddm_train_step(ctypes.byref(cs), ctypes.byref(args), ws.data_ptr(), ws.numel(),
                                      _stream_ptr(device)))
     return out

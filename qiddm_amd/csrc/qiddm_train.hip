@@ -110,7 +110,7 @@ int run_step(const qiddm_circuit_t* c, const qiddm_train_args_t* a, const Geomet
   {
     const int64_t units = a->batch * ((a->tau + qiddm::kProjLevels) / qiddm::kProjLevels) + (q ? N + 2 : 0);
     hipLaunchKernelGGL(qiddm::train_project_kernel<N>, dim3((unsigned)((units + 3) / 4)), dim3(4 * qiddm::kWave), 0,
-                       st, a->x, a->noise, a->schedule, a->w_down, a->w_up, a->b_up,
+                       st, a->x, a->noise, a->rng_state, a->schedule, a->w_down, a->w_up, a->b_up,
                        reinterpret_cast<double*>(ws + g.off_proj), a->batch, d);
     e = hipGetLastError();
     if (e != hipSuccess)
@@ -150,7 +150,7 @@ int run_step(const qiddm_circuit_t* c, const qiddm_train_args_t* a, const Geomet
                      reinterpret_cast<const double*>(ws + g.off_loss), g.n_chunks * g.tiles,
                      reinterpret_cast<const double*>(ws + g.off_gxr), reinterpret_cast<const T*>(ws + g.off_k),
                      k_blocks, a->angles, N, g.n_rot_all, wblocks, a->loss, a->g_w_down, a->g_b_down, a->g_angles,
-                     a->g_w_up, a->g_b_up, d);
+                     a->g_w_up, a->g_b_up, a->rng_state, d);
   e = hipGetLastError();
   if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "train_finalize_kernel launch failed: %s", hipGetErrorString(e));
   return QIDDM_OK;

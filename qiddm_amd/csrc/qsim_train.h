@@ -55,6 +55,29 @@ __device__ __forceinline__ double blend_noise(double xv, float nz, float w) {
   return fmin(fmax(v, 0.0), 1.0);
 }
 
+// N(0.5, 0.2) field generated in the launch (optional): Philox4x32-10 keyed by the caller's seed, counter =
+// (element index, step offset), Box-Muller on the first two words.  One value per element, so every kernel (and
+// every wavefront that needs the element) derives the same number.
+__device__ __forceinline__ float philox_normal(uint64_t seed, uint64_t offset, uint64_t index) {
+  uint32_t c0 = (uint32_t)index, c1 = (uint32_t)(index >> 32), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const float u1 = ((float)c0 + 1.0f) * 2.3283064365386963e-10f;  // (0, 1]
+  const float u2 = (float)c1 * 2.3283064365386963e-10f;           // [0, 1): revolutions
+  const float n = sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
+  return fmaf(n, 0.2f, 0.5f);
+}
+
 __device__ __forceinline__ double residual(int goal, double out, double noisy, double clean) {
   return goal == 0 ? out - clean : (out - 0.5) * 0.1 - (noisy - clean);
 }
@@ -74,9 +97,9 @@ constexpr int kProjLevels = 4;  // noise levels per wavefront: each weight fetch
 
 template <int N>
 __global__ __launch_bounds__(4 * kWave) void train_project_kernel(
-    const double* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ sched,
-    const double* __restrict__ wd, const double* __restrict__ wu, const double* __restrict__ bu,
-    double* __restrict__ proj, int64_t batch, const TrainScalars d) {
+    const double* __restrict__ x, float* __restrict__ noise, const uint64_t* __restrict__ rng,
+    const float* __restrict__ sched, const double* __restrict__ wd, const double* __restrict__ wu,
+    const double* __restrict__ bu, double* __restrict__ proj, int64_t batch, const TrainScalars d) {
   constexpr int LG = kProjLevels;
   const int P = d.pixels;
   const int lane = threadIdx.x & (kWave - 1);
@@ -108,7 +131,13 @@ __global__ __launch_bounds__(4 * kWave) void train_project_kernel(
     }
     if (kind == 0) {
       const double xv = x[b * d.x_ld + pix];
-      const float nz = noise[b * d.noise_ld + pix];
+      float nz;
+      if (rng != nullptr) {  // generate the field here; the first level group of the sample records it
+        nz = philox_normal(rng[0], rng[1], (uint64_t)b * (uint64_t)P + (uint64_t)pix);
+        if (t0 == 0) noise[b * d.noise_ld + pix] = nz;
+      } else {
+        nz = noise[b * d.noise_ld + pix];
+      }
 #pragma unroll
       for (int l = 0; l < LG; ++l) {
         const double v = blend_noise(xv, nz, w[l]);
@@ -405,7 +434,7 @@ __global__ __launch_bounds__(kWave) void train_finalize_kernel(
     const double* __restrict__ gxr, const T* __restrict__ k_partials, int64_t n_k_partials,
     const double* __restrict__ angles, int n, int64_t n_rot_all, int wblocks, double* __restrict__ loss,
     double* __restrict__ g_wd, double* __restrict__ g_bd, double* __restrict__ g_angles,
-    double* __restrict__ g_wu, double* __restrict__ g_bu, const TrainScalars d) {
+    double* __restrict__ g_wu, double* __restrict__ g_bu, uint64_t* __restrict__ rng, const TrainScalars d) {
   const int P = d.pixels;
   const int lane = threadIdx.x;
   const int role = blockIdx.x;
@@ -427,7 +456,10 @@ __global__ __launch_bounds__(kWave) void train_finalize_kernel(
 #pragma unroll 8
     for (int64_t i = lane; i < n_loss_partials; i += kWave) tot += loss_partials[i];
     tot = group_sum<double, 6>(tot, lane);
-    if (lane == 0) loss[0] = tot / ((double)d.rows * (double)P);
+    if (lane == 0) {
+      loss[0] = tot / ((double)d.rows * (double)P);
+      if (rng != nullptr) rng[1] += 1;  // next step draws a fresh field
+    }
     return;
   }
   if (role <= wblocks + n) {  // db_down[j]: one wavefront per j

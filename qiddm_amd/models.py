@@ -60,8 +60,9 @@ class Diffusion(torch.nn.Module):
             return None
         elementwise = self.loss.reduction == "none"
         schedule = sched_f(T + 1, 3.0, x.device).reshape(-1)
+        rng = getattr(self.add_noise, "rng_state", None)     # set: the field is generated inside the launch
         res = fused(x, field_f(x), schedule, self.prediction_goal, want_recon=verbose,
-                    want_elem_loss=verbose and elementwise)
+                    want_elem_loss=verbose and elementwise, **({} if rng is None else {"rng_state": rng}))
         if res is None:
             return None
         loss = res["loss"]

@@ -90,7 +90,7 @@ class _QuantumNet(nn.Module):
         linear_down -> angle-encoded circuit -> <Z> -> linear_up shape; None otherwise."""
         return None
 
-    def fused_train_step(self, x, noise, schedule, goal, want_recon=False, want_elem_loss=False):
+    def fused_train_step(self, x, noise, schedule, goal, want_recon=False, want_elem_loss=False, rng_state=None):
         """What ``Diffusion.run_training_step_*`` does around this net -- noising, forward, MSE, backward --
         in three launches (``qiddm_train_step``).  Adds the gradients to ``.grad`` exactly where ``.backward()``
         would (with ``detach_quantum`` only ``linear_up`` receives one, finding F1) and returns the dict of
@@ -106,7 +106,7 @@ class _QuantumNet(nn.Module):
         quantum = not self.detach_quantum
         res = _c.train_step(circ, x, noise, schedule, goal, lin_down.weight, lin_down.bias,
                             angles.reshape(circ.angles_shape), lin_up.weight, lin_up.bias, quantum,
-                            want_recon=want_recon, want_elem_loss=want_elem_loss)
+                            want_recon=want_recon, want_elem_loss=want_elem_loss, rng_state=rng_state)
         pairs = [(lin_up.weight, res["w_up"]), (lin_up.bias, res["b_up"])]
         if quantum:
             pairs += [(lin_down.weight, res["w_down"]), (lin_down.bias, res["b_down"]), (angles, res["angles"])]

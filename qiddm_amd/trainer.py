@@ -15,6 +15,8 @@ Adam -- once into HIP graphs and replays them:
   src/noise.py:113-115 does, then copied into the graph's static buffer (RNG-stream parity with an eager run).
 * ``noise="device"``: drawn by the device generator inside the graph (no host work per step; a different,
   equally distributed stream).
+* ``noise="fused"``: generated inside the fused training step itself (Philox4x32-10 + Box-Muller per element,
+  seeded from ``torch.initial_seed()``): no RNG launches at all.  Only for nets with a fused training step.
 * world size > 1: forward+backward and the optimizer are two graphs with the flat-bucket gradient all-reduce
   (``parallel.all_reduce_gradients``) between them -- the one exchange step of the path (section 8e).
 
@@ -38,18 +40,23 @@ class _StaticNoise:
 
     def __init__(self, owner):
         self.owner = owner
+        self.rng_state = owner.rng_state     # non-None: Diffusion hands it to the net's fused training step
 
     def noise_field(self, data):
         return self.owner._noise_field(data)
 
     def __call__(self, data, tau, decay_mod=1.0):
+        if self.owner.noise_mode == "fused":     # the net declined its fused step: draw with the device generator
+            self.owner.noise.normal_(mean=0.5, std=0.2)
         return _noise.add_normal_noise_multiple(data, tau, decay_mod, noise=self.owner._noise_field(data))
 
 
 class GraphedTrainStep:
     def __init__(self, diff, optimizer, x_example, T=10, noise="reference", verbose=False, warmup=3):
-        if noise not in ("reference", "device"):
-            raise ValueError(f"noise must be 'reference' or 'device', got {noise!r}")
+        if noise not in ("reference", "device", "fused"):
+            raise ValueError(f"noise must be 'reference', 'device' or 'fused', got {noise!r}")
+        if noise == "fused" and getattr(diff.net, "fused_train_step", None) is None:
+            raise ValueError("noise='fused' needs a net with a fused training step")
         if not x_example.is_cuda:
             raise RuntimeError("GraphedTrainStep records HIP graphs: the batch must live on the GPU")
         for group in optimizer.param_groups:
@@ -59,6 +66,10 @@ class GraphedTrainStep:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.x = x_example.detach().clone()
         self.noise = torch.empty(self.x.shape, dtype=torch.float32, device=self.x.device)
+        self.rng_state = None
+        if noise == "fused":
+            self.rng_state = torch.tensor([torch.initial_seed() & ((1 << 63) - 1), 0], dtype=torch.int64, device=self.x.device)
+            self.noise.fill_(0.5)
         self._draw_noise()
         self._user_noise_f = diff.add_noise
         params = [p for p in diff.parameters() if p.requires_grad]
@@ -102,12 +113,16 @@ class GraphedTrainStep:
             with torch.cuda.graph(self.g_fwd_bwd):
                 self._result = self._fwd_bwd()
                 self.opt.step()
+            if self.rng_state is not None:
+                self.rng_state[1] = 0           # the warm-up and the recording advanced the offset
         else:
             with torch.cuda.graph(self.g_fwd_bwd):
                 self._result = self._fwd_bwd()
             self.g_opt = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.g_opt, pool=self.g_fwd_bwd.pool()):
                 self.opt.step()
+            if self.rng_state is not None:
+                self.rng_state[1] = 0
         self._params = params
 
     def _draw_noise(self):

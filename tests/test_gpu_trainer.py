@@ -105,3 +105,30 @@ def test_graphed_step_with_fused_adam_matches_eager_torch_adam():
     assert losses_r == pytest.approx(losses_e, rel=1e-9, abs=1e-12)
     for (k, a), (_, b) in zip(eager.state_dict().items(), rec.state_dict().items()):
         assert torch.allclose(a, b, rtol=1e-7, atol=1e-10), k
+
+
+def test_fused_noise_generation():
+    """noise="fused": the N(0.5, 0.2) field is generated inside the training launch (Philox) and recorded in the
+    step's buffer -- the loss must be the eager loss on exactly that field, and every replay draws a new one."""
+    from oracle import diffusion as odf
+    from qiddm_amd.optim import FusedAdam
+    from qiddm_amd.trainer import GraphedTrainStep
+    torch.manual_seed(5)
+    diff = _make(False, "adjoint")
+    x = torch.rand(64, 64, dtype=torch.double, device="cuda")
+    step = GraphedTrainStep(diff, FusedAdam(diff.parameters(), lr=0.0), x, T=5, noise="fused")   # lr 0: weights fixed
+    fields, losses = [], []
+    for _ in range(3):
+        losses.append(step(x)[0].item())
+        fields.append(step.noise.clone())
+    assert not torch.equal(fields[0], fields[1]) and not torch.equal(fields[1], fields[2])
+    allf = torch.cat([f.flatten() for f in fields]).double()
+    assert abs(allf.mean().item() - 0.5) < 0.01 and abs(allf.std().item() - 0.2) < 0.01
+    assert abs(((allf - 0.5) / 0.2).pow(3).mean().item()) < 0.1 and abs(((allf - 0.5) / 0.2).pow(4).mean().item() - 3.0) < 0.2
+    # same numbers as the eager step on the recorded field
+    diff.net.fused_train_step = None
+    for f, want in zip(fields, losses):
+        noisy, clean = odf.training_pairs(x.cpu(), 5, (8, 8), noise=f.cpu())
+        with torch.no_grad():
+            out = diff.net(noisy.to("cuda"))
+        assert ((out.cpu() - clean) ** 2).mean().item() == pytest.approx(want, rel=1e-5)

@@ -14,7 +14,7 @@ if mode == "adjoint":
 diff = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (28, 28), torch.nn.MSELoss()).to("cuda", dtype=torch.double).train()
 x = torch.rand(256, 784, dtype=torch.double, device="cuda")
 from qiddm_amd.optim import FusedAdam
-step = GraphedTrainStep(diff, FusedAdam(diff.parameters(), lr=1e-3), x, T=10, noise="device")
+step = GraphedTrainStep(diff, FusedAdam(diff.parameters(), lr=1e-3), x, T=10, noise=os.environ.get("QIDDM_TRAIN_NOISE", "fused"))
 for _ in range(5):
     step(x)
 torch.cuda.synchronize()
