@@ -196,6 +196,20 @@ def secondary_measurements(dev, batch):
         xb = x
         with torch.no_grad():
             t = _time_fn(lambda: unet(xb), 5, warm=1)
+            try:    # the same forward recorded into a HIP graph (no allocations, no host work per replay)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    unet(xb)
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    y_static = unet(xb)
+                tg = _time_fn(g.replay, 20, warm=2)
+                if torch.allclose(y_static, unet(xb), atol=1e-9):
+                    out["denoise_images_per_s_UNetUndirectedS(3,8,3)_graphed"] = xb.shape[0] / tg
+            except Exception as e:  # pragma: no cover
+                out["unet_graph_error"] = repr(e)
         out["denoise_images_per_s_UNetUndirectedS(3,8,3)"] = xb.shape[0] / t
     except Exception as e:  # pragma: no cover
         out["unet_error"] = repr(e)
