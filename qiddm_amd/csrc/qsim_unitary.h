@@ -113,6 +113,7 @@ struct GemmConv {
   int64_t M;           // batch * Ho * Wo
   double pad_norm2;    // 0.25 * (D - F)
   double post_scale;   // D / 2
+  unsigned long long* stamps;  // diagnostics only (tools/stamp_qconv.py): s_memtime at phase ends of block 0
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -150,8 +151,7 @@ __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __r
   constexpr int kStageBytes = (kGemmK * kGemmM + kGemmK * NB) * 4;
   constexpr int kOutBytes = CT * (kGemmM + 1) * 8;
   __shared__ __attribute__((aligned(16))) unsigned char s_raw[kOutBytes > kStageBytes ? kOutBytes : kStageBytes];
-  __shared__ int s_off[kGemmMaxK];            // feature f -> offset of its tap inside one image
-  __shared__ short s_di[kGemmMaxK], s_dj[kGemmMaxK];
+  __shared__ uint32_t s_tap[kGemmMaxK];       // feature f -> offset of its tap inside one image | di << 24 | dj << 28
   __shared__ float s_n2[2][kGemmM];
   float (*s_a)[kGemmM] = reinterpret_cast<float (*)[kGemmM]>(s_raw);                       // [k][m]
   float (*s_b)[NB] = reinterpret_cast<float (*)[NB]>(s_raw + kGemmK * kGemmM * 4);          // [k][col]
@@ -159,14 +159,16 @@ __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __r
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * kGemmM;
   const int ct = blockIdx.y;  // channel tile
+  const bool stamp = g.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+  if (stamp) g.stamps[0] = __builtin_amdgcn_s_memtime();
   const int khw = g.kh * g.kw;
   const size_t plane = g.upsample ? (size_t)g.Hs * g.Ws : (size_t)g.H * g.W;
   for (int f = tid; f < g.K_pad; f += 4 * kWave) {
     const int c = f / khw, rem = f - c * khw;
     const int di = rem / g.kw, dj = rem - di * g.kw;
-    s_off[f] = g.upsample ? c : (int)(c * plane) + di * g.W + dj;  // (upsample: the channel; taps are interpolated)
-    s_di[f] = (short)di;
-    s_dj[f] = (short)dj;
+    // (upsample: the offset field carries the channel; the taps are interpolated)
+    const uint32_t off = g.upsample ? (uint32_t)c : (uint32_t)(c * plane) + (uint32_t)(di * g.W + dj);
+    s_tap[f] = off | ((uint32_t)di << 24) | ((uint32_t)dj << 28);
   }
   // ---- this thread's staging duty: row m_s, KT consecutive k of every chunk ------------------------------
   const int m_s = tid & (kGemmM - 1), kh_s = (tid >> 7) * KT;
@@ -180,18 +182,29 @@ __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __r
   const double* __restrict__ corner = img + (int64_t)oi * g.W + oj;  // tap (0, 0) of channel 0 (not dereferenced if outside)
   float n2 = 0.f;
   __syncthreads();
+  if (stamp) g.stamps[1] = __builtin_amdgcn_s_memtime();
 
   // registers of the chunk in flight: the gather for chunk k+1 is issued before the MFMAs of chunk k
   double pv[KT];
   float bv[(kGemmK * NB) / (4 * kWave)];
   auto fetch = [&](int k0) {
+    // branch-free: every load goes to a valid address (the image origin when the tap is outside) so that all KT
+    // of them are in flight together; the select happens on the loaded value
+    uint32_t tap[KT];
+#pragma unroll
+    for (int u = 0; u < KT; ++u) tap[u] = s_tap[k0 + kh_s + u];
 #pragma unroll
     for (int u = 0; u < KT; ++u) {
       const int f = k0 + kh_s + u;
-      const int ii = oi + s_di[f], jj = oj + s_dj[f];
+      const int ii = oi + (int)((tap[u] >> 24) & 15u), jj = oj + (int)(tap[u] >> 28);
+      const uint32_t off = tap[u] & 0xFFFFFFu;
       const bool in = m_ok && f < g.F && ii >= 0 && ii < g.H && jj >= 0 && jj < g.W;
-      pv[u] = 0.0;
-      if (in) pv[u] = g.upsample ? bilinear2x(img + (size_t)s_off[f] * plane, g.Hs, g.Ws, ii, jj) : corner[s_off[f]];
+      double v;
+      if (g.upsample)
+        v = bilinear2x(img + (in ? (size_t)off * plane : 0), g.Hs, g.Ws, in ? ii : 0, in ? jj : 0);
+      else
+        v = *(in ? corner + off : img);
+      pv[u] = in ? v : 0.0;
     }
 #pragma unroll
     for (int i = 0; i < (kGemmK * NB) / (4 * kWave); ++i) {
@@ -240,11 +253,12 @@ __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __r
     }
     __syncthreads();
   }
+  if (stamp) g.stamps[2] = __builtin_amdgcn_s_memtime();
   s_n2[tid >> 7][m_s] = n2;
   __syncthreads();
   // one division per pixel: D/2 over |a|^2
-  __shared__ double s_inv[kGemmM];
-  if (tid < kGemmM) s_inv[tid] = g.post_scale / ((double)s_n2[0][tid] + (double)s_n2[1][tid] + g.pad_norm2);
+  __shared__ float s_inv[kGemmM];
+  if (tid < kGemmM) s_inv[tid] = (float)(g.post_scale / ((double)s_n2[0][tid] + (double)s_n2[1][tid] + g.pad_norm2));
   __syncthreads();
   // ---- epilogue: C/D map col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) ----------------
   // |.|^2 / |a|^2 * D/2, clamp, BatchNorm -> the [channel][pixel] tile in LDS, then rows of consecutive pixels out
@@ -267,17 +281,19 @@ __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __r
         fre = acc_re[r];
         fim = acc_im[r];
       }
-      const double re = (double)(fre + pre), im = (double)(fim + pim);
-      double v = (re * re + im * im) * s_inv[ml];
-      v = fmin(fmax(v, 0.0), 1.0);
-      if (!PACKED || col < 16) s_out[cl][ml] = v * bn_scale + bn_shift;
+      // float32 until the clamp (the accumulators are float32), float64 for the normalisation that follows
+      const float re = fre + pre, im = fim + pim;
+      const float v = fminf(fmaxf((re * re + im * im) * s_inv[ml], 0.f), 1.f);
+      if (!PACKED || col < 16) s_out[cl][ml] = (double)v * bn_scale + bn_shift;
     }
   }
   __syncthreads();
+  if (stamp) g.stamps[3] = __builtin_amdgcn_s_memtime();
   if (!m_ok) return;
   const int c_live = g.C_out - ct * CT < CT ? g.C_out - ct * CT : CT;
   double* __restrict__ dst = y + ((size_t)bi * g.C_out + (size_t)ct * CT) * pixels + pix;
   for (int cl = tid >> 7; cl < c_live; cl += 2) dst[(size_t)cl * pixels] = s_out[cl][m_s];
+  if (stamp) g.stamps[4] = __builtin_amdgcn_s_memtime();
 }
 
 // ---------------------------------------------------------------------------
