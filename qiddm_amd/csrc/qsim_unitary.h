@@ -69,6 +69,7 @@ __global__ __launch_bounds__(4 * kWave) void unitary_kernel(const double* __rest
 // operand packing: W[f][col] float32, K_pad x N_pad, padv[col] = 0.5 * sum_{j >= F} (Re|Im) U[2c][j].
 //   wide   (C_out > 16): 64 columns per 32-channel tile: col = ct*64 + {0..31: Re, 32..63: Im} of channel ct*32 + (col&31)
 //   packed (C_out <= 16): 32 columns: {0..15: Re, 16..31: Im} of channel col & 15 -- one MFMA tile holds both parts
+//   packed8 (C_out <= 8): 16 columns: {0..7: Re, 8..15: Im} -- one 16x16x4 MFMA tile, no padding columns at 8 channels
 // bn[c] / bn[bn_stride + c]: eval-mode BatchNorm folded to  y * scale + shift  per channel
 // ---------------------------------------------------------------------------
 __global__ void qconv_pack_kernel(const double* __restrict__ u, int D, int F, int C_out, int K_pad, int N_pad,
@@ -77,8 +78,9 @@ __global__ void qconv_pack_kernel(const double* __restrict__ u, int D, int F, in
                                   const double* __restrict__ bn_mean, const double* __restrict__ bn_var, double bn_eps,
                                   double* __restrict__ bn, int bn_stride) {
   const int col = blockIdx.x;  // one workgroup per packed column
-  const int c = packed ? (col & 15) : (col >> 6) * 32 + (col & 31);
-  const int part = packed ? (col >> 4) & 1 : (col >> 5) & 1;
+  // packed: 0 wide, 1 = 16 channels per 32-column tile, 2 = 8 channels per 16-column tile
+  const int c = packed == 2 ? (col & 7) : packed == 1 ? (col & 15) : (col >> 6) * 32 + (col & 31);
+  const int part = packed == 2 ? (col >> 3) & 1 : packed == 1 ? (col >> 4) & 1 : (col >> 5) & 1;
   const bool live = c < C_out;
   for (int f = threadIdx.x; f < K_pad; f += blockDim.x)
     w[(size_t)f * N_pad + col] = (live && f < F) ? (float)u[((size_t)(2 * c) * D + f) * 2 + part] : 0.f;
@@ -117,6 +119,7 @@ struct GemmConv {
 };
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kGemmM = 128;  // output pixels per workgroup
 constexpr int kGemmK = 32;   // K chunk
@@ -137,15 +140,18 @@ __device__ __forceinline__ double bilinear2x(const double* __restrict__ plane, i
 
 constexpr int kGemmMaxK = 1024;  // F <= D <= 2^10 on this route
 
-// PACKED: C_out <= 16, real and imaginary columns share one 32-wide tile (one accumulator, half the MFMAs)
-template <bool PACKED>
+// MODE 0: 32 channels per workgroup, separate Re / Im tiles.  MODE 1 (C_out <= 16): Re and Im columns share one
+// 32-wide tile (one accumulator, half the MFMAs).  MODE 2 (C_out <= 8): 16 columns on v_mfma_f32_16x16x4_f32
+// (two 16-row tiles per wavefront, 32 cycles each): no padding columns at the 8-channel layers of unet_simple.
+template <int MODE>
 __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __restrict__ x,
                                                                const float* __restrict__ w,
                                                                const float* __restrict__ padv,
                                                                const double* __restrict__ bn,
                                                                double* __restrict__ y, const GemmConv g) {
-  constexpr int NB = PACKED ? 32 : 64;   // B columns per workgroup
-  constexpr int CT = PACKED ? 16 : 32;   // channels per workgroup
+  constexpr bool PACKED = MODE != 0;
+  constexpr int NB = MODE == 2 ? 16 : MODE == 1 ? 32 : 64;   // B columns per workgroup
+  constexpr int CT = MODE == 2 ? 8 : MODE == 1 ? 16 : 32;    // channels per workgroup
   constexpr int KT = kGemmK / 2;         // k values a staging thread owns per chunk
   // LDS: the staging tiles of the K loop and the output tile of the epilogue share one region
   constexpr int kStageBytes = (kGemmK * kGemmM + kGemmK * NB) * 4;
@@ -231,24 +237,42 @@ __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __r
   };
 
   f32x16 acc_re, acc_im;
+  f32x4 acc4[2];   // MODE 2: rows 0..15 and 16..31 of the wavefront's strip
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     acc_re[i] = 0.f;
     acc_im[i] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    acc4[0][i] = 0.f;
+    acc4[1][i] = 0.f;
   }
   fetch(0);
   for (int k0 = 0; k0 < g.K_pad; k0 += kGemmK) {
     stage(k0);
     __syncthreads();
     if (k0 + kGemmK < g.K_pad) fetch(k0 + kGemmK);
+    if constexpr (MODE == 2) {
+      // A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; C/D col = l & 15, row = (l >> 4) * 4 + reg
 #pragma unroll
-    for (int kk = 0; kk < kGemmK; kk += 2) {
-      const float a = s_a[kk + (lane >> 5)][wave * 32 + (lane & 31)];
-      const float bre = s_b[kk + (lane >> 5)][lane & 31];
-      acc_re = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bre, acc_re, 0, 0, 0);
-      if constexpr (!PACKED) {
-        const float bim = s_b[kk + (lane >> 5)][32 + (lane & 31)];
-        acc_im = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bim, acc_im, 0, 0, 0);
+      for (int kk = 0; kk < kGemmK; kk += 4) {
+        const float b = s_b[kk + (lane >> 4)][lane & 15];
+        const float a0 = s_a[kk + (lane >> 4)][wave * 32 + (lane & 15)];
+        const float a1 = s_a[kk + (lane >> 4)][wave * 32 + 16 + (lane & 15)];
+        acc4[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc4[0], 0, 0, 0);
+        acc4[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc4[1], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < kGemmK; kk += 2) {
+        const float a = s_a[kk + (lane >> 5)][wave * 32 + (lane & 31)];
+        const float bre = s_b[kk + (lane >> 5)][lane & 31];
+        acc_re = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bre, acc_re, 0, 0, 0);
+        if constexpr (!PACKED) {
+          const float bim = s_b[kk + (lane >> 5)][32 + (lane & 31)];
+          acc_im = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bim, acc_im, 0, 0, 0);
+        }
       }
     }
     __syncthreads();
@@ -262,7 +286,25 @@ __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __r
   __syncthreads();
   // ---- epilogue: C/D map col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) ----------------
   // |.|^2 / |a|^2 * D/2, clamp, BatchNorm -> the [channel][pixel] tile in LDS, then rows of consecutive pixels out
-  {
+  if constexpr (MODE == 2) {
+    const int col = lane & 15, cl = col & 7, c = cl;
+    const bool live = c < g.C_out;
+    const float pre = padv[cl], pim = padv[8 + cl];
+    const double bn_scale = (g.has_bn && live) ? bn[c] : 1.0, bn_shift = (g.has_bn && live) ? bn[g.bn_stride + c] : 0.0;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ml = wave * 32 + t * 16 + (lane >> 4) * 4 + r;
+        // lanes col < 8 hold Re of channel col, lanes col >= 8 hold Im of channel col - 8
+        const float other = __shfl_xor(acc4[t][r], 8, kWave);
+        const float fre = col < 8 ? acc4[t][r] : other, fim = col < 8 ? other : acc4[t][r];
+        const float re = fre + pre, im = fim + pim;
+        const float v = fminf(fmaxf((re * re + im * im) * s_inv[ml], 0.f), 1.f);
+        if (col < 8) s_out[cl][ml] = (double)v * bn_scale + bn_shift;
+      }
+    }
+  } else {
     const int col = lane & 31;
     const int cl = PACKED ? (col & 15) : col, c = ct * CT + cl;
     const bool live = c < g.C_out;
