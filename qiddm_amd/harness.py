@@ -78,6 +78,9 @@ def parse_args(argv=None):
     p.add_argument("--batch_size", type=int, default=1)
     p.add_argument("--tau-test", type=int, default=15)
     p.add_argument("--log-dir", type=str, default=None)
+    p.add_argument("--graph", action="store_true",
+                   help="record the training step (fused step + one-launch Adam) into a HIP graph and replay it; "
+                        "same numbers as the eager loop on the same noise")
     return p.parse_args(argv)
 
 
@@ -125,7 +128,15 @@ def load_model(diff, load_path, label):
 def train(diff, loader, args, start_epoch=0, loss_values=None):
     loss_values = list(loss_values or [])
     diff.train()
-    opt = torch.optim.Adam(diff.parameters(), lr=args.lr)
+    use_graph = bool(getattr(args, "graph", False)) and str(args.device).startswith("cuda")
+    if use_graph:
+        from .optim import FusedAdam
+        from .trainer import GraphedTrainStep
+        opt = FusedAdam(diff.parameters(), lr=args.lr)
+    else:
+        opt = torch.optim.Adam(diff.parameters(), lr=args.lr)
+    recorded = {}      # the shape of the first batch -> GraphedTrainStep; other shapes (an epoch's last, smaller
+                       # batch) run the same fused step eagerly with the same optimizer
     world = dist.get_world_size() if dist.is_initialized() else 1
     for _ in range(max(args.epochs - start_epoch, 0)):
         epoch_loss = torch.tensor(0.0, dtype=torch.double, device=args.device)
@@ -133,6 +144,15 @@ def train(diff, loader, args, start_epoch=0, loss_values=None):
             x = batch.to(args.device, dtype=torch.double)
             if world > 1:
                 x = parallel.shard_batch(x)
+            if use_graph and world == 1:
+                if not recorded:
+                    cpu_rng = torch.get_rng_state()        # recording draws noise too: keep the stream of the run
+                    recorded[tuple(x.shape)] = GraphedTrainStep(diff, opt, x, T=args.tau, noise="reference")
+                    torch.set_rng_state(cpu_rng)
+                step = recorded.get(tuple(x.shape))
+                if step is not None:
+                    epoch_loss += step(x)[0].mean()
+                    continue
             opt.zero_grad()
             batch_loss, _ = diff(x=x, T=args.tau, verbose=True)
             parallel.all_reduce_gradients(diff.parameters())

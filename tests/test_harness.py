@@ -69,3 +69,16 @@ def test_c1_configurations_train_on_gpu(tmp_path, model, stem):
     assert len(losses) == 3 and all(torch.isfinite(torch.tensor(losses)))
     assert losses[-1] <= losses[0] * 1.05                              # Adam is not diverging
     assert gen.shape == (5, 10, 1, 8, 8)
+
+
+@pytest.mark.gpu
+def test_graph_mode_reproduces_the_eager_run(tmp_path):
+    """--graph (recorded fused step + FusedAdam) == the eager loop: same loss curve, same trained weights."""
+    common = ["--model", "QNN_noise", "64", "4", "2", "--data", "mnist_8x8", "--img_size", "8", "--batch_size", "16",
+              "--epochs", "2", "--ds-size", "120", "--label", "0", "--tau", "5", "--device", "cuda"]
+    d1, l1, g1, _ = harness.main(common + ["--save-path", str(tmp_path / "eager")])
+    d2, l2, g2, _ = harness.main(common + ["--save-path", str(tmp_path / "graph"), "--graph"])
+    assert l2 == pytest.approx(l1, rel=1e-6)
+    for (k, a), (_, b) in zip(d1.state_dict().items(), d2.state_dict().items()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-8), k
+    assert torch.allclose(g1, g2, atol=1e-3)
