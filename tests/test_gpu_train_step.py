@@ -141,3 +141,30 @@ def test_elementwise_loss_variant_and_fallbacks():
                              "data", (8, 8), torch.nn.L1Loss()).to(DEV, dtype=torch.double).train()
     (l3,) = diff3(x=x, T=3)
     assert l3.item() > 0
+
+
+@pytest.mark.parametrize("kind,n,B,T", [("qnn", 1, 3, 2), ("qnn", 2, 1, 1), ("ll", 2, 2, 3), ("qnn", 9, 3, 2), ("ll", 9, 2, 2),
+                                        ("qnn", 10, 2, 2), ("ll", 10, 2, 1), ("qnn", 5, 70, 3)])
+def test_fused_step_edge_shapes_vs_oracle_autograd(kind, n, B, T):
+    """Smallest / largest register-resident circuits (general reverse sweep at n = 10, folded below), single rows,
+    more rows than one workgroup wave."""
+    from qiddm_amd import circuit as qc
+    side = 5
+    diff = _build(kind, False, "noise", side, n)
+    x = torch.rand(B, side * side, dtype=torch.double, device=DEV)
+    torch.manual_seed(21)
+    noise = torch.normal(mean=0.5, std=0.2, size=(B, side * side))
+    sd = {k[4:]: v for k, v in diff.state_dict().items()}
+    want_loss, want_g, _ = _oracle_step(kind, sd, x, noise, T, (side, side), "noise", False)
+    prev = qc._default_precision
+    qc.set_default_precision("f64")
+    try:
+        torch.manual_seed(21)
+        (loss,) = diff(x=x, T=T)
+    finally:
+        qc.set_default_precision(prev)
+    assert loss.item() == pytest.approx(want_loss, rel=1e-11)
+    for name, p in diff.net.named_parameters():
+        g = want_g[name]
+        scale = max(g.abs().max().item(), 1e-12)
+        assert (p.grad.cpu() - g).abs().max().item() < 1e-9 * scale + 1e-14, name
