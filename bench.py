@@ -9,8 +9,8 @@ samples are independent): BASELINE configs[1] = MNIST 28x2
 qdense ``QNN_noise(784, 8, 14)`` (reference default model, src/mnist_exm.py:48), batch 256 per
 GPU.  One step = one body of ``Diffusion.sample`` (reference src/models.py:127-134):
 ``x <- net(x)`` on a resident (256, 1, 28, 28) float64 batch, i.e.
-linear_down -> [RZ encoders + 14 x (8 Rot + 8 CZ) + <Z>] -> linear_up; `--steps-per-graph` (10)
-consecutive steps of the sampling loop run in ONE launch of the fused sampler (qiddm_dense_sample:
+linear_down -> [RZ encoders + 14 x (8 Rot + 8 CZ) + <Z>] -> linear_up; `--steps-per-graph` (15 = the
+reference's n_iters per Diffusion.sample call, src/mnist_exm.py:211) consecutive steps of the sampling loop run in ONE launch of the fused sampler (qiddm_dense_sample:
 four wavefronts per sample, the image stays in registers between steps and every intermediate image
 is written out, as Diffusion.sample records it).  Synthetic
 random-noise images (``rand*0.75+0.5``, src/mnist_exm.py:396), random-init weights under
@@ -44,8 +44,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="images per GPU per step")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
-    ap.add_argument("--steps-per-graph", type=int, default=10,
-                    help="consecutive denoise steps of the sampling loop captured per hipGraph")
+    ap.add_argument("--steps-per-graph", type=int, default=15,
+                    help="consecutive denoise steps of the sampling loop per launch of the fused sampler "
+                         "(15 = the reference's n_iters per Diffusion.sample call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (non-headline) timings")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
@@ -111,7 +112,7 @@ def make_runner(diff, x0, use_graph, steps_per_graph, launches_per_graph=5):
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         for _ in range(3):
-            chain(1, 1)
+            chain(1, steps_per_graph)
     torch.cuda.current_stream().wait_stream(side)
     shapes = {(launches_per_graph, steps_per_graph), (1, steps_per_graph), (1, 1)}
     graphs = {}
@@ -191,9 +192,9 @@ def secondary_measurements(dev, batch):
         ll = nn.QIDDM_LL_noise(IMG * IMG, 8, 6, 2).to(dev, dtype=torch.double).eval()
         # same measurement as the headline: the sampling loop, 10 consecutive steps per recorded launch
         ll_diff = models.Diffusion(ll, noise.add_normal_noise_multiple, "data", (IMG, IMG)).to(dev, dtype=torch.double).eval()
-        run, _ = make_runner(ll_diff, x, True, 10)
-        run(20)
-        t = _time_fn(lambda: run(10), 50) / 10
+        run, _ = make_runner(ll_diff, x, True, 15)
+        run(150)
+        t = _time_fn(lambda: run(75), 20) / 75
         out["denoise_images_per_s_QIDDM_LL_noise(784,8,6,2)"] = batch / t
         out["gate_apps_per_s_QIDDM_LL_noise(784,8,6,2)"] = batch * 480 / t
     except Exception as e:  # pragma: no cover

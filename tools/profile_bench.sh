@@ -12,7 +12,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT/summary
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 400 --warmup 50 --no-cpu-baseline --no-secondary"
+# steps / warmup are multiples of 75 (15 steps per launch x 5 launches per graph): every profiled launch of the
+# dominant kernel is a 15-step launch, so the per-kernel average is comparable with bench.py's own timing
+BENCH="python3 $ROOT/bench.py --steps 750 --warmup 75 --no-cpu-baseline --no-secondary"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
 echo "stats rc=$?" >> $OUT/stats.log
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_rd -- $BENCH > $OUT/pmc_rd.log 2>&1
