@@ -74,6 +74,8 @@ class GraphedTrainStep:
         self._user_noise_f = diff.add_noise
         params = [p for p in diff.parameters() if p.requires_grad]
         saved_p = [p.detach().clone() for p in params]
+        buffers = list(diff.buffers())               # e.g. BatchNorm running statistics: the warm-up must not move them
+        saved_b = [b.detach().clone() for b in buffers]
         # -- warm-up on a side stream (lazy workspaces, Adam state), then restore the initial parameters ----
         # A capturable torch optimizer keeps its step counter as a device scalar of the *default* dtype and
         # derives the bias corrections from it; with float32 that costs ~1e-5 relative in the first updates
@@ -98,6 +100,8 @@ class GraphedTrainStep:
         with torch.no_grad():
             for p, s in zip(params, saved_p):
                 p.copy_(s)
+            for b, s in zip(buffers, saved_b):
+                b.copy_(s)
             if hasattr(self.opt, "reset_state"):
                 self.opt.reset_state()
             else:

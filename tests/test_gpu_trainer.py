@@ -132,3 +132,37 @@ def test_fused_noise_generation():
         with torch.no_grad():
             out = diff.net(noisy.to("cuda"))
         assert ((out.cpu() - clean) ** 2).mean().item() == pytest.approx(want, rel=1e-5)
+
+
+def test_graphed_step_with_unet_simple_and_batchnorm_buffers():
+    """A net outside the fused step (unet_simple: QConv2d through the adjoint kernel, BatchNorm in training mode):
+    the recorded step reproduces the eager one, including the running statistics."""
+    from qiddm_amd import models, nn, noise
+    from qiddm_amd.trainer import GraphedTrainStep
+
+    def make():
+        torch.manual_seed(3)
+        net = nn.UNetUndirectedS(2, 2, 1)
+        return models.Diffusion(net, noise.add_normal_noise_multiple, "data", (8, 8),
+                                torch.nn.MSELoss()).to("cuda", dtype=torch.double).train()
+    xs = [torch.rand(3, 64, dtype=torch.double, device="cuda") for _ in range(2)]
+    eager = make()
+    opt_e = torch.optim.Adam(eager.parameters(), lr=1e-2)
+    torch.manual_seed(77)
+    le = []
+    for x in xs:
+        opt_e.zero_grad()
+        (loss,) = eager(x=x, T=2)
+        opt_e.step()
+        le.append(loss.item())
+    rec = make()
+    step = GraphedTrainStep(rec, torch.optim.Adam(rec.parameters(), lr=1e-2, capturable=True), xs[0], T=2,
+                            noise="reference")
+    torch.manual_seed(77)
+    lr_ = [step(x)[0].item() for x in xs]
+    assert lr_ == pytest.approx(le, rel=1e-7)
+    for (k, a), (_, b) in zip(eager.state_dict().items(), rec.state_dict().items()):
+        if a.dtype.is_floating_point:
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-9), k
+        else:
+            assert torch.equal(a, b), k           # num_batches_tracked
