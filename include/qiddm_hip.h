@@ -180,6 +180,13 @@ int64_t qiddm_adjoint_partials(const qiddm_circuit_t *circ, int64_t batch);
 int qiddm_backward_adjoint(const qiddm_circuit_t *circ, const void *inputs, int64_t batch,
                            int64_t in_ld, const void *gate_table, const void *grad_out, int64_t g_ld,
                            void *k_partials, void *grad_inputs, int64_t gin_ld, void *stream);
+/* n = 11..16: the same gradient with psi and lambda in a per-workgroup slab pair of `workspace`
+ * (qiddm_adjoint_workspace_bytes; 0 for n <= 10), one sweep per gate.  Same K slabs, same finalize.     */
+int64_t qiddm_adjoint_workspace_bytes(const qiddm_circuit_t *circ, int64_t batch);
+int qiddm_backward_adjoint_wide(const qiddm_circuit_t *circ, const void *inputs, int64_t batch,
+                                int64_t in_ld, const void *gate_table, const void *grad_out, int64_t g_ld,
+                                void *k_partials, void *grad_inputs, int64_t gin_ld, void *workspace,
+                                int64_t workspace_bytes, void *stream);
 /* Sums the n_partials K slabs (fixed order: deterministic) and contracts them with the analytic
  * dRot/d(phi, theta, omega) in float64: grad_angles (n_rot, 3) float64 = dL/d(angles).              */
 int qiddm_adjoint_finalize(const qiddm_circuit_t *circ, const double *angles, const void *k_partials,

@@ -41,6 +41,8 @@ EXPORTS = (
     "qiddm_adjoint_partials",
     "qiddm_backward_adjoint",
     "qiddm_adjoint_finalize",
+    "qiddm_adjoint_workspace_bytes",
+    "qiddm_backward_adjoint_wide",
     "qiddm_dense_forward",
     "qiddm_dense_sample",
     "qiddm_dense_sample_tables_bytes",
@@ -124,6 +126,10 @@ def _declare(lib):
     lib.qiddm_adjoint_partials.argtypes = [P, i64]
     lib.qiddm_backward_adjoint.restype = ctypes.c_int
     lib.qiddm_backward_adjoint.argtypes = [P, vp, i64, i64, vp, vp, i64, vp, vp, i64, vp]
+    lib.qiddm_adjoint_workspace_bytes.restype = i64
+    lib.qiddm_adjoint_workspace_bytes.argtypes = [P, i64]
+    lib.qiddm_backward_adjoint_wide.restype = ctypes.c_int
+    lib.qiddm_backward_adjoint_wide.argtypes = [P, vp, i64, i64, vp, vp, i64, vp, vp, i64, vp, i64, vp]
     lib.qiddm_adjoint_finalize.restype = ctypes.c_int
     lib.qiddm_adjoint_finalize.argtypes = [P, vp, vp, i64, vp, vp]
     lib.qiddm_qconv_forward.restype = ctypes.c_int

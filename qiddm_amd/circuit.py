@@ -542,9 +542,21 @@ def run_adjoint(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch.Ten
     gin_cols = circ.features if circ.encoding == "amplitude" else circ.n_qubits
     if with_inputs and circ.encoding != "none":
         gin = torch.empty(batch, gin_cols, dtype=dtype, device=device)
-    _capi.check(lib.qiddm_backward_adjoint(ctypes.byref(cs), x.data_ptr(), batch, ld, table.data_ptr(),
-                                           g.data_ptr(), g.shape[1], kp.data_ptr(),
-                                           0 if gin is None else gin.data_ptr(), gin_cols, _stream_ptr(device)))
+    x_ptr = 0 if x is None else x.data_ptr()
+    if circ.n_qubits > 10:
+        need = lib.qiddm_adjoint_workspace_bytes(ctypes.byref(cs), batch)
+        key = ("adjoint", device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+        ws = _workspaces.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _workspaces[key] = torch.empty(need, dtype=torch.uint8, device=device)
+        _capi.check(lib.qiddm_backward_adjoint_wide(ctypes.byref(cs), x_ptr, batch, ld, table.data_ptr(),
+                                                    g.data_ptr(), g.shape[1], kp.data_ptr(),
+                                                    0 if gin is None else gin.data_ptr(), gin_cols, ws.data_ptr(),
+                                                    ws.numel(), _stream_ptr(device)))
+    else:
+        _capi.check(lib.qiddm_backward_adjoint(ctypes.byref(cs), x_ptr, batch, ld, table.data_ptr(),
+                                               g.data_ptr(), g.shape[1], kp.data_ptr(),
+                                               0 if gin is None else gin.data_ptr(), gin_cols, _stream_ptr(device)))
     a64 = angles.detach().to(torch.float64).contiguous()
     ga = torch.empty(n_rot, 3, dtype=torch.float64, device=device)
     _capi.check(lib.qiddm_adjoint_finalize(ctypes.byref(cs), a64.data_ptr(), kp.data_ptr(), n_part,
@@ -570,11 +582,11 @@ class _QNodeFunction(torch.autograd.Function):
         inputs, angles = ctx.saved_tensors
         circ = ctx.circ
         need_in = ctx.needs_input_grad[0]
-        use_adjoint = ctx.diff_method != "parameter-shift" and circ.n_qubits <= 10
+        use_adjoint = ctx.diff_method != "parameter-shift" and circ.n_qubits <= 16
         if need_in and circ.encoding == "amplitude" and not use_adjoint:
             raise NotImplementedError(
                 "gradient w.r.t. amplitude-embedded features is not a gate parameter; "
-                "parameter-shift cannot provide it (use diff_method='backprop', n <= 10)")
+                "parameter-shift cannot provide it (use diff_method='backprop')")
         if use_adjoint:
             ga, gi = run_adjoint(circ, inputs, angles, grad_out, ctx.precision, with_inputs=need_in)
         else:
@@ -594,7 +606,8 @@ def execute(circ: Circuit, inputs, angles: torch.Tensor, precision: str | None =
     rounds run one QNode call at a time, as the reference chains them
     (nn/qdense.py:464-465); under ``torch.no_grad()`` they are fused in one launch.
     diff_method "parameter-shift": 2 kernel re-invocations per gate angle; anything else
-    ("backprop", "adjoint", "best"): the adjoint kernel (n <= 10; parameter shift beyond)."""
+    ("backprop", "adjoint", "best"): the adjoint kernels (register-resident for n <= 10, slab-resident for
+    n = 11..16)."""
     precision = precision or _default_precision
     _require_device(angles, "the circuit weights")
     needs_grad = torch.is_grad_enabled() and (

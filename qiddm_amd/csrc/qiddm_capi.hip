@@ -13,6 +13,7 @@
 #include "qsim_fused.h"
 #include "qsim_tiled.h"
 #include "qsim_adjoint.h"
+#include "qsim_adjoint_wide.h"
 #include "qsim_quad.h"
 
 namespace qiddm_capi {
@@ -498,6 +499,37 @@ int64_t out_cols(const qiddm_circuit_t* c) {
   return c->measure == QIDDM_MEAS_PROBS ? ((int64_t)1 << c->n_qubits) : c->n_qubits;
 }
 
+int64_t wide_adjoint_blocks(int64_t batch) { return batch < 1 ? 1 : (batch < 512 ? batch : 512); }
+
+template <typename T>
+int launch_wide_adjoint(const qiddm_circuit_t* c, const void* inputs, const void* table, const void* gout,
+                               void* k_partials, void* grad_inputs, void* ws, const qiddm::KScalars& p,
+                               int64_t gin_ld, hipStream_t st) {
+  const int64_t n_rot = (int64_t)c->n_blocks * c->sel_layers * c->n_qubits;
+  const size_t smem = ((size_t)n_rot * 8 + 64 + 48) * sizeof(T);
+  if (smem > kMaxLds)
+    return fail(QIDDM_ERR_UNSUPPORTED, "circuit with %lld Rot gates needs %zu B of LDS for the adjoint pass",
+                (long long)n_rot, smem);
+  auto kern = qiddm::wide_adjoint_kernel<T>;
+  static bool big_lds_enabled = false;
+  if (smem > 48 * 1024 && !big_lds_enabled) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    if (ea != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
+    big_lds_enabled = true;
+  }
+  qiddm::WideAdjointScalars ad;
+  ad.gin_ld = gin_ld;
+  ad.n = c->n_qubits;
+  ad.want_inputs = (grad_inputs != nullptr && c->encoding != QIDDM_ENC_NONE) ? 1 : 0;
+  hipLaunchKernelGGL(kern, dim3((unsigned)wide_adjoint_blocks(p.batch)), dim3(qiddm::kWideThreads), smem, st,
+                     static_cast<const T*>(inputs), static_cast<const T*>(table), static_cast<const T*>(gout),
+                     static_cast<T*>(k_partials), static_cast<T*>(grad_inputs), static_cast<qiddm::V2<T>*>(ws), p, ad);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "wide_adjoint_kernel launch failed: %s", hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -661,8 +693,42 @@ int qiddm_forward_shifted(const qiddm_circuit_t* c, const void* inputs, int64_t 
 
 int64_t qiddm_adjoint_partials(const qiddm_circuit_t* c, int64_t batch) {
   if (check_circuit(c) != QIDDM_OK || batch < 0) return -1;
-  if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED) return -1;
+  if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED) return wide_adjoint_blocks(batch);
   return adjoint_blocks_n(c->n_qubits, batch);
+}
+
+int64_t qiddm_adjoint_workspace_bytes(const qiddm_circuit_t* c, int64_t batch) {
+  if (check_circuit(c) != QIDDM_OK || batch < 0) return -1;
+  if (c->n_qubits <= QIDDM_MAX_QUBITS_FUSED) return 0;
+  return wide_adjoint_blocks(batch) * 2 * ((int64_t)1 << c->n_qubits) * (c->dtype == QIDDM_F32 ? 8 : 16);
+}
+
+int qiddm_backward_adjoint_wide(const qiddm_circuit_t* c, const void* inputs, int64_t batch, int64_t in_ld,
+                                const void* gate_table, const void* grad_out, int64_t g_ld, void* k_partials,
+                                void* grad_inputs, int64_t gin_ld, void* workspace, int64_t workspace_bytes,
+                                void* stream) {
+  int rc = check_circuit(c);
+  if (rc != QIDDM_OK) return rc;
+  if (c->n_rounds != 1)
+    return fail(QIDDM_ERR_UNSUPPORTED, "the adjoint pass differentiates one QNode round (n_rounds=%d)", c->n_rounds);
+  if (c->n_qubits <= QIDDM_MAX_QUBITS_FUSED)
+    return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d: use qiddm_backward_adjoint (register-resident)", c->n_qubits);
+  if (batch < 0) return fail(QIDDM_ERR_INVALID, "batch < 0");
+  if (!gate_table || !grad_out || !k_partials) return fail(QIDDM_ERR_INVALID, "gate_table/grad_out/k_partials is NULL");
+  if (c->encoding != QIDDM_ENC_NONE && batch > 0 && !inputs) return fail(QIDDM_ERR_INVALID, "inputs is NULL");
+  if (g_ld < out_cols(c)) return fail(QIDDM_ERR_INVALID, "g_ld smaller than the output row");
+  const int64_t need = qiddm_adjoint_workspace_bytes(c, batch);
+  if (!workspace || workspace_bytes < need)
+    return fail(QIDDM_ERR_INVALID, "workspace of %lld B needed (qiddm_adjoint_workspace_bytes), got %lld",
+                (long long)need, (long long)workspace_bytes);
+  qiddm::KScalars p = make_params(c);
+  p.in_ld = in_ld;
+  p.g_ld = g_ld;
+  p.batch = batch;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return c->dtype == QIDDM_F32
+             ? launch_wide_adjoint<float>(c, inputs, gate_table, grad_out, k_partials, grad_inputs, workspace, p, gin_ld, st)
+             : launch_wide_adjoint<double>(c, inputs, gate_table, grad_out, k_partials, grad_inputs, workspace, p, gin_ld, st);
 }
 
 int qiddm_backward_adjoint(const qiddm_circuit_t* c, const void* inputs, int64_t batch, int64_t in_ld,

@@ -453,7 +453,7 @@ struct Engine {
       FoldedLayer nxt;
       {
         const int ln = first_layer + li + 1;
-        load_folded(ln < n_layers_all ? ln : 0, N > 1 ? s % (N - 1) : -1, nxt);
+        load_folded(ln < n_layers_all ? ln : 0, N > 1 ? s % (N > 1 ? N - 1 : 1) : -1, nxt);
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {

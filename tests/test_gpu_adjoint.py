@@ -104,3 +104,68 @@ def test_differn_backprop_training_step():
     ref.sum().backward()
     assert torch.allclose(out.detach().cpu(), ref.detach(), atol=1e-9)
     assert torch.allclose(m.weights.grad.cpu().double(), w.grad.double(), atol=1e-7)
+
+
+@pytest.mark.parametrize("n,enc,imp,meas", [(11, "rz", "CZ", "expz"), (11, "amplitude", "CNOT", "probs"), (12, "rz", "CZ", "probs"),
+                                            (12, "ry", "CNOT", "expz"), (13, "rz", "CNOT", "expz"), (12, "ry_blocks", "CZ", "probs")])
+def test_wide_adjoint_vs_oracle_autograd(n, enc, imp, meas):
+    """n = 11..13: psi and lambda in the workspace slabs (qiddm_backward_adjoint_wide) -- weights, angle inputs and
+    amplitude-embedded inputs against autograd through the oracle."""
+    from oracle import circuits as oc
+    from qiddm_amd.circuit import Circuit, execute
+    torch.manual_seed(n * 3 + len(enc))
+    blocks, layers, B = (2, 2, 3) if enc in ("rz", "ry_blocks") else (1, 3, 3)
+    feat = 1500 if enc == "amplitude" else n
+    circ = Circuit(n_qubits=n, encoding=enc, imprimitive=imp, measure=meas, n_rounds=1, n_blocks=blocks,
+                   sel_layers=layers, n_features=feat if enc == "amplitude" else 0, pad_with=0.3)
+    w = (torch.randn(circ.angles_shape, dtype=torch.float64) * 0.5)
+    x = None if enc == "none" else (torch.rand(B, feat, dtype=torch.float64) + 0.1)
+    g = torch.randn(B if x is not None else 1, (1 << n) if meas == "probs" else n, dtype=torch.float64)
+    # oracle
+    wo = w.clone().requires_grad_(True)
+    xo = None if x is None else x.clone().requires_grad_(True)
+    spec = oc.Spec(n=n, encoding=enc, imprimitive=imp, measure=meas, pad_with=0.3)
+    xin = xo if xo is not None else torch.zeros(1, n, dtype=torch.float64)
+    out_o = oc.run_circuit(spec, xin, wo)
+    (out_o * g).sum().backward()
+    # product (float64 kernels)
+    wd = w.to("cuda").requires_grad_(True)
+    xd = None if x is None else x.to("cuda").requires_grad_(True)
+    out_d = execute(circ, xd, wd, "f64", "backprop")
+    assert (out_d.cpu() - out_o.detach()).abs().max().item() < 1e-11
+    (out_d * g.to("cuda")).sum().backward()
+    scale = max(wo.grad.abs().max().item(), 1e-12)
+    assert (wd.grad.cpu() - wo.grad).abs().max().item() < 1e-9 * scale + 1e-13
+    if xo is not None:
+        sx = max(xo.grad.abs().max().item(), 1e-12)
+        assert (xd.grad.cpu() - xo.grad).abs().max().item() < 1e-9 * sx + 1e-13
+
+
+def test_twelve_qubit_qconv_trains_through_the_wide_adjoint():
+    """BASELINE config 4's layer shape (C_in = 256, 3x3 -> 2304 features -> 12 wires): weight and input gradients of
+    QConv2d against autograd through the oracle (before the wide adjoint existed this raised NotImplementedError)."""
+    from oracle import circuits as oc
+    from qiddm_amd import circuit as qc
+    from qiddm_amd import nn
+    torch.manual_seed(4)
+    layer = nn.QConv2d(256, 4, qdepth=1).to("cuda").train()
+    assert layer.wires == 12
+    x = torch.rand(1, 256, 3, 3, dtype=torch.float64)
+    g = torch.randn(1, 4, 3, 3, dtype=torch.float64)
+    wo = layer.weights.detach().cpu().clone().requires_grad_(True)
+    xo = x.clone().requires_grad_(True)
+    yo = oc.qconv2d_forward(xo, wo, 4, (3, 3), (1, 1))
+    (yo * g).sum().backward()
+    prev = qc._default_precision
+    qc.set_default_precision("f64")
+    try:
+        xd = x.to("cuda").requires_grad_(True)
+        yd = layer(xd)
+        assert (yd.cpu() - yo.detach()).abs().max().item() < 1e-10
+        (yd * g.to("cuda")).sum().backward()
+    finally:
+        qc.set_default_precision(prev)
+    sw = max(wo.grad.abs().max().item(), 1e-12)
+    assert (layer.weights.grad.cpu() - wo.grad).abs().max().item() < 1e-8 * sw
+    sx = max(xo.grad.abs().max().item(), 1e-12)
+    assert (xd.grad.cpu() - xo.grad).abs().max().item() < 1e-8 * sx

@@ -48,7 +48,8 @@ def main():
               f" {eq:8.2f} TB/s HBM-equivalent", flush=True)
     print("== backward (one round), f32 ==")
     for tag, n, L, S, B in [("QNN_noise(784,8,14) round", 8, 1, 14, 2560), ("LL(784,8,6,2) round", 8, 6, 2, 2560),
-                            ("differN(28,9,2) round", 10, 9, 2, 1024)]:
+                            ("differN(28,9,2) round", 10, 9, 2, 1024), ("12q LL round (wide adjoint)", 12, 6, 2, 1024),
+                            ("C5 16q LL round (wide adjoint)", 16, 6, 2, 128)]:
         meas = "probs" if n == 10 else "expz"
         circ = Circuit(n_qubits=n, encoding="rz", imprimitive="CZ", measure=meas, n_blocks=L, sel_layers=S)
         w = (torch.randn(circ.angles_shape, dtype=torch.float64) * 0.4).to(DEV)
@@ -56,7 +57,7 @@ def main():
         gout = torch.randn(B, circ.out_cols, device=DEV)
         tf = t_eager(lambda: run_forward(circ, x, w, "f32"))
         ta = t_eager(lambda: run_adjoint(circ, x, w, gout, "f32"))
-        ts = t_eager(lambda: run_shift_sweep(circ, x, w, gout, "f32"), iters=2, warm=1)
+        ts = t_eager(lambda: run_shift_sweep(circ, x, w, gout, "f32"), iters=1 if n > 10 else 2, warm=0 if n > 10 else 1)
         print(f"{tag:30s} B={B}: forward {tf * 1e3:8.3f} ms  adjoint {ta * 1e3:8.3f} ms  parameter-shift {ts * 1e3:9.2f} ms "
               f"({ts / ta:6.1f}x)", flush=True)
 
