@@ -334,12 +334,15 @@ typedef struct qiddm_batchnorm {
   double eps;
 } qiddm_batchnorm_t;
 int qiddm_circuit_unitary(const qiddm_circuit_t *circ, const double *angles, double *u, void *stream);
+/* n <= 12 (C4's 12-qubit layers): writes the TRANSPOSE, ut[j][k] = <k|U|j> (each column of U contiguous: the
+ * workgroup of column j evolves |j> in place in row j, no workspace).  Pass u_transposed = 1 below.          */
+int qiddm_circuit_unitary_wide(const qiddm_circuit_t *circ, const double *angles, double *ut, void *stream);
 int64_t qiddm_qconv_unitary_workspace_bytes(int32_t n_qubits, int64_t in_channels, int64_t kh, int64_t kw,
                                             int64_t out_channels);
 int qiddm_qconv_unitary_forward(int32_t n_qubits, const double *u, const double *x, int64_t batch,
                                 int64_t in_channels, int64_t height, int64_t width, int64_t kh, int64_t kw,
                                 int64_t pad_h, int64_t pad_w, int64_t out_channels, int32_t upsample2x,
-                                const qiddm_batchnorm_t *bn, double *y, void *workspace,
+                                const qiddm_batchnorm_t *bn, int32_t u_transposed, double *y, void *workspace,
                                 int64_t workspace_bytes, void *stream);
 
 /* classical 1x1 convolution, float64 NCHW (the UNets' `final_conv`, reference nn/unet.py:160-166):

@@ -52,6 +52,7 @@ EXPORTS = (
     "qiddm_train_step",
     "qiddm_adam_step",
     "qiddm_circuit_unitary",
+    "qiddm_circuit_unitary_wide",
     "qiddm_qconv_unitary_workspace_bytes",
     "qiddm_qconv_unitary_forward",
     "qiddm_conv1x1_forward",
@@ -140,11 +141,14 @@ def _declare(lib):
     lib.qiddm_train_step.argtypes = [P, ctypes.POINTER(TrainArgs), vp, i64, vp]
     lib.qiddm_circuit_unitary.restype = ctypes.c_int
     lib.qiddm_circuit_unitary.argtypes = [P, vp, vp, vp]
+    lib.qiddm_circuit_unitary_wide.restype = ctypes.c_int
+    lib.qiddm_circuit_unitary_wide.argtypes = [P, vp, vp, vp]
     lib.qiddm_qconv_unitary_workspace_bytes.restype = i64
     lib.qiddm_qconv_unitary_workspace_bytes.argtypes = [ctypes.c_int32, i64, i64, i64, i64]
     lib.qiddm_qconv_unitary_forward.restype = ctypes.c_int
     lib.qiddm_qconv_unitary_forward.argtypes = [ctypes.c_int32, vp, vp, i64, i64, i64, i64, i64, i64, i64, i64,
-                                                i64, ctypes.c_int32, ctypes.POINTER(BatchNormStruct), vp, vp, i64, vp]
+                                                i64, ctypes.c_int32, ctypes.POINTER(BatchNormStruct), ctypes.c_int32, vp, vp,
+                                                i64, vp]
     lib.qiddm_mixed_workspace_bytes.restype = i64
     lib.qiddm_mixed_workspace_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32, i64, ctypes.c_int32]
     lib.qiddm_mixed_forward.restype = ctypes.c_int

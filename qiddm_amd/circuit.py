@@ -282,7 +282,7 @@ def circuit_unitary(angles: torch.Tensor, n_qubits: int, imprimitive: str = "CNO
                     precision: str = "f64") -> torch.Tensor:
     """``qml.matrix`` of ``StronglyEntanglingLayers(angles (S, n, 3), imprimitive)`` with
     ``wire_order=range(n)`` (reference nn/qconv.py:96-103): (D, D) complex128 on the device
-    (``qiddm_circuit_unitary``).  One wavefront per column; n <= 10."""
+    (``qiddm_circuit_unitary``; ``qiddm_circuit_unitary_wide`` for n = 11, 12, returned as a transposed view)."""
     _require_device(angles, "the circuit weights")
     device = angles.device
     ang = _as_f64(angles, device)
@@ -293,6 +293,12 @@ def circuit_unitary(angles: torch.Tensor, n_qubits: int, imprimitive: str = "CNO
     d = 1 << n_qubits
     u = torch.empty(d, d, 2, dtype=torch.float64, device=device)
     cs = circ.c_struct(precision)
+    if n_qubits > 10:
+        # the wide kernel writes U^T (columns contiguous); hand back the transposed view: indexing is <k|U|j> as
+        # below, and qconv_unitary_forward recognises the layout
+        _capi.check(_capi.lib().qiddm_circuit_unitary_wide(ctypes.byref(cs), ang.data_ptr(), u.data_ptr(),
+                                                           _stream_ptr(device)))
+        return torch.view_as_complex(u).transpose(0, 1)
     _capi.check(_capi.lib().qiddm_circuit_unitary(ctypes.byref(cs), ang.data_ptr(), u.data_ptr(),
                                                   _stream_ptr(device)))
     return torch.view_as_complex(u)
@@ -321,7 +327,8 @@ def qconv_unitary_forward(x: torch.Tensor, unitary: torch.Tensor, n_qubits: int,
     if tuple(unitary.shape) != (d, d) or unitary.dtype != torch.complex128:
         raise ValueError(f"unitary must be ({d}, {d}) complex128; got {tuple(unitary.shape)} {unitary.dtype}")
     xx = _as_f64(x, device).contiguous()
-    ur = torch.view_as_real(unitary.contiguous())
+    transposed = (not unitary.is_contiguous()) and unitary.transpose(0, 1).is_contiguous()
+    ur = torch.view_as_real(unitary.transpose(0, 1) if transposed else unitary.contiguous())
     lib = _capi.lib()
     need = lib.qiddm_qconv_unitary_workspace_bytes(n_qubits, c, kh, kw, out_channels)
     if need < 0:
@@ -350,7 +357,7 @@ def qconv_unitary_forward(x: torch.Tensor, unitary: torch.Tensor, n_qubits: int,
                                           running_var=f64(batch_norm.running_var), eps=float(batch_norm.eps))
         bn_ref = ctypes.byref(bn_struct)
     _capi.check(lib.qiddm_qconv_unitary_forward(n_qubits, ur.data_ptr(), xx.data_ptr(), b, c, h, w, kh, kw, ph, pw,
-                                                out_channels, int(bool(upsample2x)), bn_ref, y.data_ptr(),
+                                                out_channels, int(bool(upsample2x)), bn_ref, int(transposed), y.data_ptr(),
                                                 ws.data_ptr(), ws.numel(), _stream_ptr(device)))
     return y
 

@@ -85,8 +85,8 @@ struct ConvGeometry {
 
 int conv_geometry(int n_qubits, int64_t batch, int64_t in_channels, int64_t height, int64_t width, int64_t kh,
                   int64_t kw, int64_t pad_h, int64_t pad_w, int64_t out_channels, ConvGeometry* g) {
-  if (n_qubits < 1 || n_qubits > QIDDM_MAX_QUBITS)
-    return fail(QIDDM_ERR_INVALID, "n_qubits=%d out of range", n_qubits);
+  if (n_qubits < 1 || n_qubits > 12)
+    return fail(QIDDM_ERR_UNSUPPORTED, "the unitary route covers n_qubits <= 12 (got %d)", n_qubits);
   if (batch < 0 || in_channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad_h < 0 || pad_w < 0 ||
       out_channels < 1)
     return fail(QIDDM_ERR_INVALID, "bad convolution geometry");
@@ -126,6 +126,23 @@ int qiddm_circuit_unitary(const qiddm_circuit_t* circ, const double* angles, dou
                                   : dispatch_unitary<double>(circ, angles, u, st);
 }
 
+int qiddm_circuit_unitary_wide(const qiddm_circuit_t* circ, const double* angles, double* ut, void* stream) {
+  int rc = check_circuit(circ);
+  if (rc != QIDDM_OK) return rc;
+  if (circ->n_rounds != 1 || circ->n_blocks != 1)
+    return fail(QIDDM_ERR_UNSUPPORTED, "the circuit unitary is defined for one round and one block of weight-only layers");
+  if (circ->n_qubits < 2 || circ->n_qubits > 12)
+    return fail(QIDDM_ERR_UNSUPPORTED, "qiddm_circuit_unitary_wide covers 2 <= n_qubits <= 12 (got %d)", circ->n_qubits);
+  if (!angles || !ut) return fail(QIDDM_ERR_INVALID, "angles/ut is NULL");
+  const unsigned d = 1u << circ->n_qubits;
+  hipLaunchKernelGGL(qiddm::wide_unitary_kernel<0>, dim3(d < 2048 ? d : 2048), dim3(qiddm::kWideThreads), 0,
+                     static_cast<hipStream_t>(stream), angles, reinterpret_cast<qiddm::V2<double>*>(ut), circ->n_qubits,
+                     circ->sel_layers, circ->imprimitive == QIDDM_IMP_CNOT ? 1 : 0);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "wide_unitary_kernel launch failed: %s", hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
 int64_t qiddm_qconv_unitary_workspace_bytes(int32_t n_qubits, int64_t in_channels, int64_t kh, int64_t kw,
                                             int64_t out_channels) {
   ConvGeometry g;
@@ -137,8 +154,8 @@ int64_t qiddm_qconv_unitary_workspace_bytes(int32_t n_qubits, int64_t in_channel
 int qiddm_qconv_unitary_forward(int32_t n_qubits, const double* u, const double* x, int64_t batch,
                                 int64_t in_channels, int64_t height, int64_t width, int64_t kh, int64_t kw,
                                 int64_t pad_h, int64_t pad_w, int64_t out_channels, int32_t upsample2x,
-                                const qiddm_batchnorm_t* bn, double* y, void* workspace, int64_t workspace_bytes,
-                                void* stream) {
+                                const qiddm_batchnorm_t* bn, int32_t u_transposed, double* y, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
   // with upsample2x the stored image is (height, width) and the convolution sees its bilinear x2
   const int64_t h_eff = upsample2x ? 2 * height : height, w_eff = upsample2x ? 2 * width : width;
   ConvGeometry g;
@@ -158,7 +175,7 @@ int qiddm_qconv_unitary_forward(int32_t n_qubits, const double* u, const double*
   double* bnv = reinterpret_cast<double*>(ws + g.off_bn);
   const int d = 1 << n_qubits;
   const int f = (int)(in_channels * kh * kw);
-  hipLaunchKernelGGL(qiddm::qconv_pack_kernel, dim3((unsigned)g.n_pad), dim3(256), 0, st, u, d, f,
+  hipLaunchKernelGGL(qiddm::qconv_pack_kernel, dim3((unsigned)g.n_pad), dim3(256), 0, st, u, u_transposed ? 1 : 0, d, f,
                      (int)out_channels, (int)g.k_pad, (int)g.n_pad, g.packed, w, padv,
                      bn ? bn->weight : nullptr, bn ? bn->bias : nullptr, bn ? bn->running_mean : nullptr,
                      bn ? bn->running_var : nullptr, bn ? bn->eps : 0.0, bnv, (int)(g.n_pad / 2));

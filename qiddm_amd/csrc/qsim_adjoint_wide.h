@@ -293,4 +293,64 @@ __global__ __launch_bounds__(kWideThreads) void wide_adjoint_kernel(const T* __r
   for (int i = tid; i < n_rot * 8; i += kWideThreads) k_partials[(size_t)blockIdx.x * n_rot * 8 + i] = s_k[i];
 }
 
+// ---------------------------------------------------------------------------
+// U^T of a weight-only StronglyEntanglingLayers circuit for n = 11, 12 (the eval-mode QConv2d route of C4): one
+// workgroup per column j evolves |j> IN PLACE in row j of the output (complex128), so that row j of `ut` is column j
+// of U and no workspace is needed.  ut[j * D + k] = <k|U|j>.
+// ---------------------------------------------------------------------------
+template <int UNUSED = 0>  // (a template only for linkage: the header is included by two translation units)
+__global__ __launch_bounds__(kWideThreads) void wide_unitary_kernel(const double* __restrict__ angles,
+                                                                    V2<double>* __restrict__ ut, int n, int sel_layers,
+                                                                    int use_cnot) {
+  using C = V2<double>;
+  const int tid = threadIdx.x;
+  const uint32_t D = 1u << n;
+  for (uint32_t j = blockIdx.x; j < D; j += gridDim.x) {
+    C* psi = ut + (size_t)j * D;
+    for (uint32_t k = tid; k < D; k += kWideThreads) psi[k] = C{k == j ? 1.0 : 0.0, 0.0};
+    __syncthreads();
+    for (int s = 0; s < sel_layers; ++s) {
+      for (int w = 0; w < n; ++w) {
+        const double* a = angles + ((size_t)s * n + w) * 3;
+        double c, sn, ca, sa, cb, sb;
+        sincos(0.5 * a[1], &sn, &c);
+        sincos(0.5 * (a[0] + a[2]), &sa, &ca);
+        sincos(0.5 * (a[0] - a[2]), &sb, &cb);
+        const C u00{ca * c, -sa * c}, u01{-cb * sn, -sb * sn}, u10{cb * sn, -sb * sn}, u11{ca * c, sa * c};
+        const int q = n - 1 - w;
+        const uint32_t bit = 1u << q;
+        for (uint32_t t = tid; t < D / 2; t += kWideThreads) {
+          const uint32_t i0 = ((t >> q) << (q + 1)) | (t & (bit - 1)), i1 = i0 | bit;
+          const C a0 = psi[i0], a1 = psi[i1];
+          psi[i0] = wmul<double>(u00, a0) + wmul<double>(u01, a1);
+          psi[i1] = wmul<double>(u10, a0) + wmul<double>(u11, a1);
+        }
+        __syncthreads();
+      }
+      const int rr = s % (n - 1) + 1;
+      if (!use_cnot) {
+        const uint32_t dmask = D - 1u;
+        for (uint32_t k = tid; k < D; k += kWideThreads) {
+          const uint32_t rot = ((k << rr) | (k >> (n - rr))) & dmask;
+          if (__popc(k & rot) & 1) psi[k] = C{-psi[k].x, -psi[k].y};
+        }
+        __syncthreads();
+      } else {
+        for (int i = 0; i < n; ++i) {
+          const int qc = n - 1 - i, qt = n - 1 - (i + rr) % n;
+          for (uint32_t k = tid; k < D; k += kWideThreads) {
+            if (((k >> qc) & 1u) && !((k >> qt) & 1u)) {
+              const uint32_t k1 = k | (1u << qt);
+              const C tmp = psi[k];
+              psi[k] = psi[k1];
+              psi[k1] = tmp;
+            }
+          }
+          __syncthreads();
+        }
+      }
+    }
+  }
+}
+
 }  // namespace qiddm

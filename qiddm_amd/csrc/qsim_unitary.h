@@ -17,6 +17,7 @@
 //                       4 wavefronts x (32 x 32 re, 32 x 32 im) accumulators, K staged through LDS 16 at a time.
 #pragma once
 #include "qsim_adjoint.h"
+#include "qsim_adjoint_wide.h"
 
 namespace qiddm {
 
@@ -72,8 +73,9 @@ __global__ __launch_bounds__(4 * kWave) void unitary_kernel(const double* __rest
 //   packed8 (C_out <= 8): 16 columns: {0..7: Re, 8..15: Im} -- one 16x16x4 MFMA tile, no padding columns at 8 channels
 // bn[c] / bn[bn_stride + c]: eval-mode BatchNorm folded to  y * scale + shift  per channel
 // ---------------------------------------------------------------------------
-__global__ void qconv_pack_kernel(const double* __restrict__ u, int D, int F, int C_out, int K_pad, int N_pad,
-                                  int packed, float* __restrict__ w, float* __restrict__ padv,
+// u_transposed: u holds U^T (u[j][k] = <k|U|j>, what qiddm_circuit_unitary_wide writes)
+__global__ void qconv_pack_kernel(const double* __restrict__ u, int u_transposed, int D, int F, int C_out, int K_pad,
+                                  int N_pad, int packed, float* __restrict__ w, float* __restrict__ padv,
                                   const double* __restrict__ bn_weight, const double* __restrict__ bn_bias,
                                   const double* __restrict__ bn_mean, const double* __restrict__ bn_var, double bn_eps,
                                   double* __restrict__ bn, int bn_stride) {
@@ -83,11 +85,14 @@ __global__ void qconv_pack_kernel(const double* __restrict__ u, int D, int F, in
   const int part = packed == 2 ? (col >> 3) & 1 : packed == 1 ? (col >> 4) & 1 : (col >> 5) & 1;
   const bool live = c < C_out;
   for (int f = threadIdx.x; f < K_pad; f += blockDim.x)
-    w[(size_t)f * N_pad + col] = (live && f < F) ? (float)u[((size_t)(2 * c) * D + f) * 2 + part] : 0.f;
+    w[(size_t)f * N_pad + col] = (live && f < F) ? (float)(u_transposed ? u[((size_t)f * D + 2 * c) * 2 + part]
+                                                                         : u[((size_t)(2 * c) * D + f) * 2 + part])
+                                                 : 0.f;
   __shared__ double s_part[256];
   double acc = 0.0;
   if (live)
-    for (int j = F + threadIdx.x; j < D; j += blockDim.x) acc += u[((size_t)(2 * c) * D + j) * 2 + part];
+    for (int j = F + threadIdx.x; j < D; j += blockDim.x)
+      acc += u_transposed ? u[((size_t)j * D + 2 * c) * 2 + part] : u[((size_t)(2 * c) * D + j) * 2 + part];
   s_part[threadIdx.x] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -138,7 +143,7 @@ __device__ __forceinline__ double bilinear2x(const double* __restrict__ plane, i
   return h0l * (w0l * r0[0] + w1l * r0[w1p]) + h1l * (w0l * r1[0] + w1l * r1[w1p]);
 }
 
-constexpr int kGemmMaxK = 1024;  // F <= D <= 2^10 on this route
+constexpr int kGemmMaxK = 4096;  // F <= D <= 2^12 on this route
 
 // MODE 0: 32 channels per workgroup, separate Re / Im tiles.  MODE 1 (C_out <= 16): Re and Im columns share one
 // 32-wide tile (one accumulator, half the MFMAs).  MODE 2 (C_out <= 8): 16 columns on v_mfma_f32_16x16x4_f32

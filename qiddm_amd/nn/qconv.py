@@ -62,6 +62,11 @@ class QConv2d(torch.nn.Module):
         assert c == self.in_channels, f"Expected {self.in_channels} channels, got {c}"
         h_out = h_in + 2 * self.padding[0] - self.kernel_size[0] + 1
         w_out = w_in + 2 * self.padding[1] - self.kernel_size[1] + 1
+        if (not torch.is_grad_enabled() and self.qnode is self._own_qnode and self.wires <= 12 and not self.training
+                and x.is_cuda and _c._default_precision == "f32" and 2 * self.out_channels <= 2 ** self.wires):
+            # eval mode (reference :92-126), up to C4's 12 wires: the cached circuit unitary, then one GEMM
+            return _c.qconv_unitary_forward(x, self._eval_unitary(), self.wires, self.out_channels,
+                                            self.kernel_size, self.padding)
         if (not torch.is_grad_enabled() and self.qnode is self._own_qnode and self.wires <= 10
                 and 2 * self.out_channels <= 2 ** self.wires):
             if not self.training and x.is_cuda and _c._default_precision == "f32":
@@ -81,7 +86,7 @@ class QConv2d(torch.nn.Module):
         (``upsample2x``: the bilinear x2 in front of an ``up_conv``; ``batch_norm``: the eval-mode BatchNorm2d behind
         a ``net`` convolution).  None when this layer or the call is outside that route."""
         if torch.is_grad_enabled() or self.training or self.qnode is not self._own_qnode or not x.is_cuda \
-                or self.wires > 10 or 2 * self.out_channels > 2 ** self.wires or x.shape[1] != self.in_channels:
+                or self.wires > 12 or 2 * self.out_channels > 2 ** self.wires or x.shape[1] != self.in_channels:
             return None
         if _c._default_precision != "f32":
             return None      # the GEMM multiplies in float32; the float64 setting keeps the float64 circuit kernel

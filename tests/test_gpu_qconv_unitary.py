@@ -179,3 +179,33 @@ def test_float64_setting_keeps_the_float64_circuit_kernel():
     finally:
         qc.set_default_precision(prev)
     assert (got - want).abs().max().item() < 1e-11
+
+
+def test_wide_unitary_and_twelve_qubit_eval_convolution():
+    """n = 11 circuit unitary (written transposed, returned as a view) against the oracle, and BASELINE config 4's
+    12-wire layer shape (C_in = 256, 3x3, 64 output channels) through the eval-mode GEMM route."""
+    from oracle import circuits as oc
+    from oracle import statevector as sv
+    from qiddm_amd import circuit as qc
+    from qiddm_amd import nn
+    torch.manual_seed(11)
+    n = 11
+    w = torch.randn(2, n, 3, dtype=torch.float64) * 0.8
+    d = 1 << n
+    cols = sv.strongly_entangling_layers(torch.eye(d, dtype=torch.complex128).reshape((d,) + (2,) * n), w, n, "CNOT")
+    want = cols.reshape(d, d).T
+    got = qc.circuit_unitary(w.to(DEV), n, "CNOT", precision="f64")
+    assert got.shape == (d, d) and not got.is_contiguous()
+    assert (got.cpu() - want).abs().max().item() < 1e-12
+    layer = nn.QConv2d(256, 64, qdepth=2).to(DEV).eval()
+    assert layer.wires == 12
+    x = torch.rand(1, 256, 4, 4, dtype=torch.float64, device=DEV)
+    ref = oc.qconv2d_forward(x.cpu(), layer.weights.detach().cpu(), 64, (3, 3), (1, 1))
+    with torch.no_grad():
+        y = layer(x)
+        layer.train()
+        y_sim = layer(x)                       # tiled circuit simulation, one workgroup per pixel
+    assert layer.sample_matrix is None
+    tol = 2e-5 * (2 ** 12 / 2) / 8
+    assert (y.cpu() - ref).abs().max().item() < tol
+    assert (y_sim.cpu() - ref).abs().max().item() < tol
