@@ -104,8 +104,10 @@ int conv_geometry(int n_qubits, int64_t batch, int64_t in_channels, int64_t heig
   g->m = batch * g->ho * g->wo;
   if (g->m >= ((int64_t)1 << 38)) return fail(QIDDM_ERR_INVALID, "too many output pixels");
   g->k_pad = (f + qiddm::kGemmK - 1) / qiddm::kGemmK * qiddm::kGemmK;
-  g->packed = out_channels <= 8 ? 2 : out_channels <= 16 ? 1 : 0;
-  g->n_pad = g->packed == 2 ? 16 : g->packed == 1 ? 32 : (out_channels + 31) / 32 * 64;
+  // 3: four 32-channel tiles per workgroup (many channels: the gather is shared by 128 channels)
+  g->packed = out_channels <= 8 ? 2 : out_channels <= 16 ? 1 : out_channels >= 96 ? 3 : 0;
+  g->n_pad = g->packed == 2 ? 16 : g->packed == 1 ? 32
+             : g->packed == 3 ? (out_channels + 127) / 128 * 256 : (out_channels + 31) / 32 * 64;
   g->off_w = 0;
   g->off_padv = (g->k_pad * g->n_pad * 4 + 255) / 256 * 256;
   g->off_bn = g->off_padv + (g->n_pad * 4 + 255) / 256 * 256;
@@ -176,7 +178,7 @@ int qiddm_qconv_unitary_forward(int32_t n_qubits, const double* u, const double*
   const int d = 1 << n_qubits;
   const int f = (int)(in_channels * kh * kw);
   hipLaunchKernelGGL(qiddm::qconv_pack_kernel, dim3((unsigned)g.n_pad), dim3(256), 0, st, u, u_transposed ? 1 : 0, d, f,
-                     (int)out_channels, (int)g.k_pad, (int)g.n_pad, g.packed, w, padv,
+                     (int)out_channels, (int)g.k_pad, (int)g.n_pad, g.packed == 3 ? 0 : g.packed, w, padv,
                      bn ? bn->weight : nullptr, bn ? bn->bias : nullptr, bn ? bn->running_mean : nullptr,
                      bn ? bn->running_var : nullptr, bn ? bn->eps : 0.0, bnv, (int)(g.n_pad / 2));
   hipError_t e = hipGetLastError();
@@ -206,7 +208,10 @@ int qiddm_qconv_unitary_forward(int32_t n_qubits, const double* u, const double*
   if (const char* ev = std::getenv("QIDDM_STAMP_PTR")) gc.stamps = reinterpret_cast<unsigned long long*>(std::strtoull(ev, nullptr, 0));
   const int64_t mblocks = (g.m + qiddm::kGemmM - 1) / qiddm::kGemmM;
   if (mblocks > 0x7fffffff) return fail(QIDDM_ERR_UNSUPPORTED, "too many output pixels for one launch");
-  if (g.packed == 2)
+  if (g.packed == 3)
+    hipLaunchKernelGGL(qiddm::qconv_gemm_wide_kernel, dim3((unsigned)mblocks, (unsigned)(g.n_pad / 256)),
+                       dim3(4 * qiddm::kWave), 0, st, x, w, padv, bnv, y, gc);
+  else if (g.packed == 2)
     hipLaunchKernelGGL(qiddm::qconv_gemm_kernel<2>, dim3((unsigned)mblocks, 1u), dim3(4 * qiddm::kWave), 0, st, x, w,
                        padv, bnv, y, gc);
   else if (g.packed == 1)

@@ -344,6 +344,151 @@ __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __r
 }
 
 // ---------------------------------------------------------------------------
+// many output channels (C4: 256): the gather of a K chunk is the expensive part of qconv_gemm_kernel<0>, and with one
+// 32-channel tile per workgroup it is repeated by every channel tile.  Here a workgroup keeps kWideSub = 4 channel tiles
+// (128 channels: 8 accumulator tiles per wavefront) per staged A chunk, so four times the MFMA work rides on every
+// gather; K is staged 16 at a time to keep the LDS footprint.  Same operand layout (wide packing), same epilogue.
+// ---------------------------------------------------------------------------
+constexpr int kWideSub = 4;
+constexpr int kWideK = 16;
+
+__global__ __launch_bounds__(4 * kWave, 2) void qconv_gemm_wide_kernel(const double* __restrict__ x,
+                                                                    const float* __restrict__ w,
+                                                                    const float* __restrict__ padv,
+                                                                    const double* __restrict__ bn,
+                                                                    double* __restrict__ y, const GemmConv g) {
+  constexpr int NBW = 64 * kWideSub;  // B columns per workgroup
+  constexpr int KT = kWideK / 2;
+  constexpr int kStageBytes = (kWideK * kGemmM + kWideK * NBW) * 4;
+  constexpr int kOutBytes = 32 * (kGemmM + 1) * 8;
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[kOutBytes > kStageBytes ? kOutBytes : kStageBytes];
+  __shared__ uint32_t s_tap[kGemmMaxK];
+  __shared__ float s_n2[2][kGemmM];
+  __shared__ float s_inv[kGemmM];
+  float (*s_a)[kGemmM] = reinterpret_cast<float (*)[kGemmM]>(s_raw);
+  float (*s_b)[NBW] = reinterpret_cast<float (*)[NBW]>(s_raw + kWideK * kGemmM * 4);
+  double (*s_out)[kGemmM + 1] = reinterpret_cast<double (*)[kGemmM + 1]>(s_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t m0 = (int64_t)blockIdx.x * kGemmM;
+  const int ct0 = blockIdx.y * kWideSub;  // first 32-channel tile of this workgroup
+  const int khw = g.kh * g.kw;
+  const size_t plane = g.upsample ? (size_t)g.Hs * g.Ws : (size_t)g.H * g.W;
+  for (int f = tid; f < g.K_pad; f += 4 * kWave) {
+    const int c = f / khw, rem = f - c * khw;
+    const int di = rem / g.kw, dj = rem - di * g.kw;
+    const uint32_t off = g.upsample ? (uint32_t)c : (uint32_t)(c * plane) + (uint32_t)(di * g.W + dj);
+    s_tap[f] = off | ((uint32_t)di << 24) | ((uint32_t)dj << 28);
+  }
+  const int m_s = tid & (kGemmM - 1), kh_s = (tid >> 7) * KT;
+  const int64_t mg = m0 + m_s;
+  const bool m_ok = mg < g.M;
+  const int64_t pixels = (int64_t)g.Ho * g.Wo;
+  const int64_t bi = m_ok ? mg / pixels : 0;
+  const int pix = m_ok ? (int)(mg - bi * pixels) : 0;
+  const int oi = pix / g.Wo - g.ph, oj = pix % g.Wo - g.pw;
+  const double* __restrict__ img = x + (size_t)bi * g.C * plane;
+  const double* __restrict__ corner = img + (int64_t)oi * g.W + oj;
+  float n2 = 0.f;
+  __syncthreads();
+
+  double pv[KT];
+  float bv[(kWideK * NBW) / (4 * kWave)];
+  auto fetch = [&](int k0) {
+    uint32_t tap[KT];
+#pragma unroll
+    for (int u = 0; u < KT; ++u) tap[u] = s_tap[k0 + kh_s + u];
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+      const int f = k0 + kh_s + u;
+      const int ii = oi + (int)((tap[u] >> 24) & 15u), jj = oj + (int)(tap[u] >> 28);
+      const uint32_t off = tap[u] & 0xFFFFFFu;
+      const bool in = m_ok && f < g.F && ii >= 0 && ii < g.H && jj >= 0 && jj < g.W;
+      double v;
+      if (g.upsample)
+        v = bilinear2x(img + (in ? (size_t)off * plane : 0), g.Hs, g.Ws, in ? ii : 0, in ? jj : 0);
+      else
+        v = *(in ? corner + off : img);
+      pv[u] = in ? v : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < (kWideK * NBW) / (4 * kWave); ++i) {
+      const int e = tid + i * 4 * kWave;
+      bv[i] = w[(size_t)(k0 + e / NBW) * g.N_pad + ct0 * 64 + (e % NBW)];
+    }
+  };
+  auto stage = [&](int k0) {
+#pragma unroll
+    for (int u = 0; u < KT; ++u) {
+      const int f = k0 + kh_s + u;
+      float v = 0.f;
+      if (m_ok && f < g.F) {
+        v = (float)(pv[u] + 0.1);
+        n2 = fmaf(v, v, n2);
+      }
+      s_a[kh_s + u][m_s] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < (kWideK * NBW) / (4 * kWave); ++i) {
+      const int e = tid + i * 4 * kWave;
+      s_b[e / NBW][e % NBW] = bv[i];
+    }
+  };
+
+  f32x16 acc_re[kWideSub], acc_im[kWideSub];
+#pragma unroll
+  for (int sub = 0; sub < kWideSub; ++sub)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      acc_re[sub][i] = 0.f;
+      acc_im[sub][i] = 0.f;
+    }
+  fetch(0);
+  for (int k0 = 0; k0 < g.K_pad; k0 += kWideK) {
+    stage(k0);
+    __syncthreads();
+    if (k0 + kWideK < g.K_pad) fetch(k0 + kWideK);
+#pragma unroll
+    for (int kk = 0; kk < kWideK; kk += 2) {
+      const float a = s_a[kk + (lane >> 5)][wave * 32 + (lane & 31)];
+#pragma unroll
+      for (int sub = 0; sub < kWideSub; ++sub) {
+        const float bre = s_b[kk + (lane >> 5)][sub * 64 + (lane & 31)];
+        const float bim = s_b[kk + (lane >> 5)][sub * 64 + 32 + (lane & 31)];
+        acc_re[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bre, acc_re[sub], 0, 0, 0);
+        acc_im[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bim, acc_im[sub], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  s_n2[tid >> 7][m_s] = n2;
+  __syncthreads();
+  if (tid < kGemmM) s_inv[tid] = (float)(g.post_scale / ((double)s_n2[0][tid] + (double)s_n2[1][tid] + g.pad_norm2));
+  __syncthreads();
+#pragma unroll
+  for (int sub = 0; sub < kWideSub; ++sub) {
+    const int ct = ct0 + sub;
+    const int col = lane & 31, c = ct * 32 + col;
+    const bool live = c < g.C_out;
+    const float pre = padv[ct * 64 + col], pim = padv[ct * 64 + 32 + col];
+    const double bn_scale = (g.has_bn && live) ? bn[c] : 1.0, bn_shift = (g.has_bn && live) ? bn[g.bn_stride + c] : 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const float re = acc_re[sub][r] + pre, im = acc_im[sub][r] + pim;
+      const float v = fminf(fmaxf((re * re + im * im) * s_inv[ml], 0.f), 1.f);
+      s_out[col][ml] = (double)v * bn_scale + bn_shift;
+    }
+    __syncthreads();
+    if (m_ok) {
+      const int c_live = g.C_out - ct * 32 < 32 ? g.C_out - ct * 32 : 32;
+      double* __restrict__ dst = y + ((size_t)bi * g.C_out + (size_t)ct * 32) * pixels + pix;
+      for (int cl = tid >> 7; cl < c_live; cl += 2) dst[(size_t)cl * pixels] = s_out[cl][m_s];
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------
 // classical 1x1 convolution in float64 (the `final_conv` of the UNets, reference nn/unet.py:160-166): one thread
 // per output pixel, all output channels; x (B, C_in, HW), w (C_out, C_in), y (B, C_out, HW)
 // ---------------------------------------------------------------------------

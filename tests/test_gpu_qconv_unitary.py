@@ -36,6 +36,7 @@ CASES = [  # (C_in, C_out, k, pad, H, W, B, qdepth)
     (8, 40, 3, 0, 8, 8, 1, 1),        # n = 7, two channel tiles, no padding
     (1, 1, 1, 0, 4, 4, 1, 1),         # n = 1: the single even-index probability
     (48, 64, 3, 1, 6, 6, 1, 1),       # n = 9, K = 432, two channel tiles
+    (48, 200, 3, 1, 6, 5, 2, 1),      # n = 9, 200 channels: the 128-channels-per-workgroup kernel, ragged last group
 ]
 
 
