@@ -222,6 +222,22 @@ def secondary_measurements(dev, batch):
         out["denoise_images_per_s_UNetUndirectedS(3,8,3)"] = xb.shape[0] / t
     except Exception as e:  # pragma: no cover
         out["unet_error"] = repr(e)
+    try:
+        # BASELINE config 4's layer: 12-qubit QConv2d(256 -> 256, 3x3, qdepth 3), eval mode = the one GEMM of the path
+        # (implicit-im2col 65536 x 2304 by 2304 x 512 on the f32 MFMA); bound: mfma
+        torch.manual_seed(42)
+        conv = nn.QConv2d(256, 256, qdepth=3).to(dev).eval()
+        xc = torch.rand(64, 256, 32, 32, dtype=torch.double, device=dev)
+        with torch.no_grad():
+            t = _time_fn(lambda: conv(xc), 5, warm=1)
+        px = xc.shape[0] * 32 * 32
+        tf = 2.0 * 2304 * 512 * px / t / 1e12
+        out["qconv12_eval_pixels_per_s"] = px / t
+        out["qconv12_roofline"] = {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+                                   "kernel": "qiddm::qconv_gemm_wide_kernel"}
+        del conv, xc
+    except Exception as e:  # pragma: no cover
+        out["qconv12_error"] = repr(e)
     for tag, detach in (("as_written_F1", True), ("parameter_shift", False), ("adjoint", False)):
         try:
             torch.manual_seed(42)
