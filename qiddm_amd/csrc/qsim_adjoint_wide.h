@@ -91,16 +91,20 @@ __global__ __launch_bounds__(kWideThreads) void wide_adjoint_kernel(const T* __r
     }
     __syncthreads();
   };
-  auto cz_ring = [&](C* v, int rr) {
+  // ring operations act on v and (when given) on v2 in the same sweep: one barrier for both vectors
+  auto cz_ring = [&](C* v, C* v2, int rr) {
     const uint32_t dmask = D - 1u;
     for (uint32_t k = tid; k < D; k += kWideThreads) {
       const uint32_t rot = ((k << rr) | (k >> (n - rr))) & dmask;
-      if (__popc(k & rot) & 1) v[k] = C{-v[k].x, -v[k].y};
+      if (__popc(k & rot) & 1) {
+        v[k] = C{-v[k].x, -v[k].y};
+        if (v2) v2[k] = C{-v2[k].x, -v2[k].y};
+      }
     }
     __syncthreads();
   };
   // CNOT(c, t) is its own inverse; a ring applies i = 0..n-1 in order, its inverse in reverse order
-  auto cnot = [&](C* v, int c, int t_) {
+  auto cnot = [&](C* v, C* v2, int c, int t_) {
     const int qc = n - 1 - c, qt = n - 1 - t_;
     for (uint32_t k = tid; k < D; k += kWideThreads) {
       if (((k >> qc) & 1u) && !((k >> qt) & 1u)) {
@@ -108,25 +112,30 @@ __global__ __launch_bounds__(kWideThreads) void wide_adjoint_kernel(const T* __r
         const C tmp = v[k];
         v[k] = v[k1];
         v[k1] = tmp;
+        if (v2) {
+          const C tmp2 = v2[k];
+          v2[k] = v2[k1];
+          v2[k1] = tmp2;
+        }
       }
     }
     __syncthreads();
   };
   auto ring_fwd = [&](C* v, int rr) {
     if (!use_cnot) {
-      cz_ring(v, rr);
+      cz_ring(v, nullptr, rr);
     } else {
-      for (int i = 0; i < n; ++i) cnot(v, i, (i + rr) % n);
+      for (int i = 0; i < n; ++i) cnot(v, nullptr, i, (i + rr) % n);
     }
   };
-  auto ring_back = [&](C* v, int rr) {
+  auto ring_back = [&](C* v, C* v2, int rr) {
     if (!use_cnot) {
-      cz_ring(v, rr);
+      cz_ring(v, v2, rr);
     } else {
-      for (int i = n - 1; i >= 0; --i) cnot(v, i, (i + rr) % n);
+      for (int i = n - 1; i >= 0; --i) cnot(v, v2, i, (i + rr) % n);
     }
   };
-  auto rz_layer = [&](C* v, bool conj) {  // diag prod_w exp(-+ i x_w / 2)
+  auto rz_layer = [&](C* v, C* v2, bool conj) {  // diag prod_w exp(-+ i x_w / 2)
     for (uint32_t k = tid; k < D; k += kWideThreads) {
       T fr = 1, fi = 0;
       for (int q = 0; q < n; ++q) {
@@ -138,6 +147,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_adjoint_kernel(const T* __r
         fr = nr;
       }
       v[k] = wmul<T>(C{fr, fi}, v[k]);
+      if (v2) v2[k] = wmul<T>(C{fr, fi}, v2[k]);
     }
     __syncthreads();
   };
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_adjoint_kernel(const T* __r
     __syncthreads();
     for (int blk = 0; blk < p.n_blocks; ++blk) {
       if (p.encoding == 2) {
-        rz_layer(psi, false);
+        rz_layer(psi, nullptr, false);
       } else if ((p.encoding == 3 && blk == 0) || p.encoding == 4) {
         for (int w = 0; w < n; ++w) {
           const T c = s_cs[w], s = s_sn[w];
@@ -209,8 +219,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_adjoint_kernel(const T* __r
     // ---- reverse sweep ----------------------------------------------------------------------------------------------
     for (int blk = p.n_blocks - 1; blk >= 0; --blk) {
       for (int s = p.sel_layers - 1; s >= 0; --s) {
-        ring_back(psi, s % (n - 1) + 1);
-        ring_back(lam, s % (n - 1) + 1);
+        ring_back(psi, lam, s % (n - 1) + 1);
         const int gate0 = (blk * p.sel_layers + s) * n;
         for (int w = n - 1; w >= 0; --w) {
           C u[4];
@@ -247,8 +256,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_adjoint_kernel(const T* __r
             if (w < n) gw[w] += ((k >> (n - 1 - w)) & 1u) ? -t : t;
         }
         block_accumulate<T, 16>(gw, s_red, s_gx);
-        rz_layer(psi, true);
-        rz_layer(lam, true);
+        rz_layer(psi, lam, true);
       } else if ((p.encoding == 3 && blk == 0) || p.encoding == 4) {
         for (int w = n - 1; w >= 0; --w) {
           const T c = s_cs[w], sn = s_sn[w];
