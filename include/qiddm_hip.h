@@ -251,6 +251,21 @@ int qiddm_qconv_forward(const qiddm_circuit_t *circ, const double *x, int64_t ba
                         int64_t pad_h, int64_t pad_w, const double *angles, int64_t out_channels,
                         double *y, void *stream);
 
+/* Backward of qiddm_qconv_forward in two launches (replaces torch autograd through Unfold, default.qubit.torch
+ * and the post-processing slices, reference nn/qconv.py:46, 58-87 with diff_method="backprop"): the adjoint
+ * sweep runs one circuit per output pixel with the patch read from x and dL/dp read from grad_y
+ * (B, out_channels, H_out, W_out) through the clamp / [::2] / [:out_channels] chain, never materialising the
+ * (B H_out W_out, 2^n) probability gradient; then the per-pixel feature gradients are folded back onto the image.
+ *   gate_table : qiddm_prepare_gates of the (1,1,S,n,3) angles (after the tanh map), circ->dtype
+ *   k_partials : (qiddm_adjoint_partials(circ, batch*H_out*W_out), n_rot, 8) circ->dtype -> qiddm_adjoint_finalize
+ *   grad_features : scratch (batch*H_out*W_out, in_channels*kh*kw) circ->dtype; grad_x: (batch, C, H, W) float64.
+ *                   Both NULL when the input needs no gradient.
+ * n_qubits <= 10.                                                                                          */
+int qiddm_qconv_backward(const qiddm_circuit_t *circ, const double *x, int64_t batch, int64_t in_channels,
+                         int64_t height, int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
+                         const void *gate_table, const double *grad_y, int64_t out_channels, void *k_partials,
+                         void *grad_features, double *grad_x, void *stream);
+
 /* ---- fused training step (device-resident Diffusion step) ---------------------------------
  * Replaces, for nets of the linear_down -> circuit -> linear_up family (QNN_noise nn/qdense.py:267-289,
  * QIDDM_LL_noise :1620-1642), one call of Diffusion.run_training_step_data / _noise

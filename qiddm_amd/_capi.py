@@ -48,6 +48,7 @@ EXPORTS = (
     "qiddm_dense_sample_tables_bytes",
     "qiddm_dense_sample_prepare",
     "qiddm_qconv_forward",
+    "qiddm_qconv_backward",
     "qiddm_train_workspace_bytes",
     "qiddm_train_step",
     "qiddm_adam_step",
@@ -135,6 +136,8 @@ def _declare(lib):
     lib.qiddm_adjoint_finalize.argtypes = [P, vp, vp, i64, vp, vp]
     lib.qiddm_qconv_forward.restype = ctypes.c_int
     lib.qiddm_qconv_forward.argtypes = [P, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, vp, vp]
+    lib.qiddm_qconv_backward.restype = ctypes.c_int
+    lib.qiddm_qconv_backward.argtypes = [P, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, vp, i64, vp, vp, vp, vp]
     lib.qiddm_train_workspace_bytes.restype = ctypes.c_int64
     lib.qiddm_train_workspace_bytes.argtypes = [P, i64, ctypes.c_int32, ctypes.c_int32]
     lib.qiddm_train_step.restype = ctypes.c_int

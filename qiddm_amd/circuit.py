@@ -478,6 +478,77 @@ def qconv_forward(x: torch.Tensor, angles: torch.Tensor, n_qubits: int, out_chan
     return y
 
 
+def _qconv_circuit(n_qubits, sel_layers, features):
+    return Circuit(n_qubits=n_qubits, encoding="amplitude", imprimitive="CNOT", measure="probs",
+                   n_rounds=1, n_blocks=1, sel_layers=sel_layers, n_features=features,
+                   enc_offset=0.1, pad_with=0.5)
+
+
+def qconv_backward(x: torch.Tensor, angles: torch.Tensor, grad_y: torch.Tensor, n_qubits: int, kernel_size, padding,
+                   precision: str | None = None, with_input: bool = True):
+    """Gradients of :func:`qconv_forward` (``qiddm_qconv_backward`` + ``qiddm_adjoint_finalize``).
+    Returns (grad_angles (S, n, 3) float64, grad_x like x float64 or None)."""
+    precision = precision or _default_precision
+    dtype = _DT[precision][1]
+    device = angles.device
+    b, c, h, w = x.shape
+    kh, kw = kernel_size
+    ph, pw = padding
+    out_channels = grad_y.shape[1]
+    circ = _qconv_circuit(n_qubits, angles.shape[0], c * kh * kw)
+    xx = _as_f64(x, device)
+    gy = _as_f64(grad_y, device)
+    ang = _as_f64(angles, device)
+    ho, wo = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+    m = b * ho * wo
+    lib = _capi.lib()
+    cs = circ.c_struct(precision)
+    table = prepare_gates(circ, ang.reshape(circ.angles_shape), precision)
+    n_rot = lib.qiddm_num_rot_gates(ctypes.byref(cs))
+    n_part = lib.qiddm_adjoint_partials(ctypes.byref(cs), m)
+    if n_part < 0:
+        _capi.check(-2)
+    kp = torch.empty(n_part, n_rot, 8, dtype=dtype, device=device)
+    gfeat = gx = None
+    if with_input:
+        gfeat = torch.empty(m, c * kh * kw, dtype=dtype, device=device)
+        gx = torch.empty(b, c, h, w, dtype=torch.float64, device=device)
+    _capi.check(lib.qiddm_qconv_backward(ctypes.byref(cs), xx.data_ptr(), b, c, h, w, kh, kw, ph, pw,
+                                         table.data_ptr(), gy.data_ptr(), out_channels, kp.data_ptr(),
+                                         0 if gfeat is None else gfeat.data_ptr(),
+                                         0 if gx is None else gx.data_ptr(), _stream_ptr(device)))
+    ga = torch.empty(n_rot, 3, dtype=torch.float64, device=device)
+    _capi.check(lib.qiddm_adjoint_finalize(ctypes.byref(cs), ang.data_ptr(), kp.data_ptr(), n_part,
+                                           ga.data_ptr(), _stream_ptr(device)))
+    return ga.reshape(angles.shape), gx
+
+
+class _QConvFunction(torch.autograd.Function):
+    """The intended QConv2d layer (reference nn/qconv.py:51-87, finding F3) as one differentiable op: forward is
+    the fused convolution launch, backward the adjoint sweep over the output pixels + the fold onto the image."""
+
+    @staticmethod
+    def forward(ctx, x, angles, n_qubits, out_channels, kernel_size, padding, precision):
+        ctx.save_for_backward(x, angles)
+        ctx.cfg = (n_qubits, kernel_size, padding, precision)
+        return qconv_forward(x, angles.detach(), n_qubits, out_channels, kernel_size, padding, precision)
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, angles = ctx.saved_tensors
+        n_qubits, kernel_size, padding, precision = ctx.cfg
+        ga, gx = qconv_backward(x, angles.detach(), grad_y, n_qubits, kernel_size, padding, precision,
+                                with_input=ctx.needs_input_grad[0])
+        return (None if gx is None else gx.to(x.dtype)), ga.to(angles.dtype), None, None, None, None, None
+
+
+def qconv_execute(x: torch.Tensor, angles: torch.Tensor, n_qubits: int, out_channels: int, kernel_size, padding,
+                  precision: str | None = None) -> torch.Tensor:
+    """Differentiable :func:`qconv_forward` (n <= 10)."""
+    return _QConvFunction.apply(x, angles, n_qubits, out_channels, tuple(kernel_size), tuple(padding),
+                                precision or _default_precision)
+
+
 def run_shift_sweep(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch.Tensor,
                     precision: str | None = None, with_inputs: bool = True,
                     max_dots_elems: int = 1 << 26):

@@ -365,9 +365,15 @@ int64_t adjoint_blocks_n(int n, int64_t batch) {
   }
 }
 
-template <typename T, int N>
+struct ConvPtrs {  // quantum-convolution backward: image, dL/dy and geometry (unused otherwise)
+  const double* img = nullptr;
+  const double* gy = nullptr;
+  qiddm::ConvScalars cv{};
+};
+
+template <typename T, int N, bool CONV>
 int launch_adjoint(const Ptrs& ptr, T* k_partials, T* grad_inputs, const qiddm::KScalars& p,
-                   const qiddm::AdjointScalars& ad, hipStream_t stream) {
+                   const qiddm::AdjointScalars& ad, const ConvPtrs& conv, hipStream_t stream) {
   using S = qiddm::Smem<T, N>;
   const int waves = 4;
   const int64_t n_rot = (int64_t)p.n_blocks * p.sel_layers * N;
@@ -376,7 +382,7 @@ int launch_adjoint(const Ptrs& ptr, T* k_partials, T* grad_inputs, const qiddm::
   if (smem > kMaxLds)
     return fail(QIDDM_ERR_UNSUPPORTED, "circuit with %lld Rot gates needs %zu B of LDS for the adjoint pass",
                 (long long)n_rot, smem);
-  auto kern = qiddm::adjoint_kernel<T, N>;
+  auto kern = qiddm::adjoint_kernel<T, N, CONV>;
   static bool big_lds_enabled = false;
   if (smem > 48 * 1024 && !big_lds_enabled) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -387,29 +393,29 @@ int launch_adjoint(const Ptrs& ptr, T* k_partials, T* grad_inputs, const qiddm::
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)adjoint_blocks<N>(p.batch)), dim3(waves * qiddm::kWave), smem, stream,
                      static_cast<const T*>(ptr.inputs), static_cast<const T*>(ptr.table),
-                     static_cast<const T*>(ptr.gout), k_partials, grad_inputs, p, ad);
+                     static_cast<const T*>(ptr.gout), k_partials, grad_inputs, p, ad, conv.img, conv.gy, conv.cv);
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess)
     return fail(QIDDM_ERR_LAUNCH, "adjoint_kernel<n=%d> launch failed: %s", N, hipGetErrorString(e));
   return QIDDM_OK;
 }
 
-template <typename T>
+template <typename T, bool CONV>
 int dispatch_adjoint(int n, const Ptrs& ptr, void* kp, void* gi, const qiddm::KScalars& p,
-                     const qiddm::AdjointScalars& ad, hipStream_t st) {
+                     const qiddm::AdjointScalars& ad, const ConvPtrs& conv, hipStream_t st) {
   T* k = static_cast<T*>(kp);
   T* g = static_cast<T*>(gi);
   switch (n) {
-    case 1: return launch_adjoint<T, 1>(ptr, k, g, p, ad, st);
-    case 2: return launch_adjoint<T, 2>(ptr, k, g, p, ad, st);
-    case 3: return launch_adjoint<T, 3>(ptr, k, g, p, ad, st);
-    case 4: return launch_adjoint<T, 4>(ptr, k, g, p, ad, st);
-    case 5: return launch_adjoint<T, 5>(ptr, k, g, p, ad, st);
-    case 6: return launch_adjoint<T, 6>(ptr, k, g, p, ad, st);
-    case 7: return launch_adjoint<T, 7>(ptr, k, g, p, ad, st);
-    case 8: return launch_adjoint<T, 8>(ptr, k, g, p, ad, st);
-    case 9: return launch_adjoint<T, 9>(ptr, k, g, p, ad, st);
-    case 10: return launch_adjoint<T, 10>(ptr, k, g, p, ad, st);
+    case 1: return launch_adjoint<T, 1, CONV>(ptr, k, g, p, ad, conv, st);
+    case 2: return launch_adjoint<T, 2, CONV>(ptr, k, g, p, ad, conv, st);
+    case 3: return launch_adjoint<T, 3, CONV>(ptr, k, g, p, ad, conv, st);
+    case 4: return launch_adjoint<T, 4, CONV>(ptr, k, g, p, ad, conv, st);
+    case 5: return launch_adjoint<T, 5, CONV>(ptr, k, g, p, ad, conv, st);
+    case 6: return launch_adjoint<T, 6, CONV>(ptr, k, g, p, ad, conv, st);
+    case 7: return launch_adjoint<T, 7, CONV>(ptr, k, g, p, ad, conv, st);
+    case 8: return launch_adjoint<T, 8, CONV>(ptr, k, g, p, ad, conv, st);
+    case 9: return launch_adjoint<T, 9, CONV>(ptr, k, g, p, ad, conv, st);
+    case 10: return launch_adjoint<T, 10, CONV>(ptr, k, g, p, ad, conv, st);
     default: return fail(QIDDM_ERR_UNSUPPORTED, "adjoint backward needs n_qubits <= 10 (got %d)", n);
   }
 }
@@ -766,8 +772,82 @@ int qiddm_backward_adjoint(const qiddm_circuit_t* c, const void* inputs, int64_t
   ad.pad_ = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   // batch == 0 still has to zero the (single) partial slab: launch with no samples
-  return c->dtype == QIDDM_F32 ? dispatch_adjoint<float>(c->n_qubits, ptr, k_partials, grad_inputs, p, ad, st)
-                               : dispatch_adjoint<double>(c->n_qubits, ptr, k_partials, grad_inputs, p, ad, st);
+  const ConvPtrs none;
+  return c->dtype == QIDDM_F32
+             ? dispatch_adjoint<float, false>(c->n_qubits, ptr, k_partials, grad_inputs, p, ad, none, st)
+             : dispatch_adjoint<double, false>(c->n_qubits, ptr, k_partials, grad_inputs, p, ad, none, st);
+}
+
+int qiddm_qconv_backward(const qiddm_circuit_t* c, const double* x, int64_t batch, int64_t in_channels,
+                         int64_t height, int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
+                         const void* gate_table, const double* grad_y, int64_t out_channels, void* k_partials,
+                         void* grad_features, double* grad_x, void* stream) {
+  int rc = check_circuit(c);
+  if (rc != QIDDM_OK) return rc;
+  if (c->encoding != QIDDM_ENC_AMPLITUDE || c->measure != QIDDM_MEAS_PROBS || c->n_rounds != 1 ||
+      c->n_blocks != 1)
+    return fail(QIDDM_ERR_UNSUPPORTED, "QConv2d needs amplitude encoding, probs, one round, one block");
+  if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED)
+    return fail(QIDDM_ERR_UNSUPPORTED, "fused QConv2d backward needs n_qubits <= %d (got %d)",
+                QIDDM_MAX_QUBITS_FUSED, c->n_qubits);
+  if (batch < 0 || in_channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad_h < 0 || pad_w < 0 ||
+      out_channels < 1)
+    return fail(QIDDM_ERR_INVALID, "bad convolution geometry");
+  if (in_channels * kh * kw != c->n_features)
+    return fail(QIDDM_ERR_INVALID, "n_features=%d != in_channels*kh*kw=%lld", c->n_features,
+                (long long)(in_channels * kh * kw));
+  const int64_t ho = height + 2 * pad_h - kh + 1, wo = width + 2 * pad_w - kw + 1;
+  if (ho < 1 || wo < 1) return fail(QIDDM_ERR_INVALID, "kernel larger than the padded image");
+  const int64_t d = (int64_t)1 << c->n_qubits;
+  if (2 * out_channels > d && !(d == 2 && out_channels == 1))
+    return fail(QIDDM_ERR_INVALID, "out_channels=%lld exceeds the %lld even-index probabilities",
+                (long long)out_channels, (long long)(d / 2));
+  if (batch * ho * wo >= ((int64_t)1 << 40)) return fail(QIDDM_ERR_INVALID, "too many output pixels");
+  if (!gate_table || !k_partials) return fail(QIDDM_ERR_INVALID, "gate_table/k_partials is NULL");
+  if (batch > 0 && (!x || !grad_y)) return fail(QIDDM_ERR_INVALID, "x/grad_y is NULL");
+  if ((grad_x != nullptr) != (grad_features != nullptr))
+    return fail(QIDDM_ERR_INVALID, "grad_x and grad_features go together (both or neither)");
+  qiddm::KScalars p = make_params(c);
+  p.batch = batch * ho * wo;  // one circuit per output pixel
+  p.in_ld = c->n_features;
+  p.g_ld = d;
+  ConvPtrs conv;
+  conv.img = x;
+  conv.gy = grad_y;
+  std::memset(&conv.cv, 0, sizeof(conv.cv));
+  conv.cv.C = (int32_t)in_channels;
+  conv.cv.H = (int32_t)height;
+  conv.cv.W = (int32_t)width;
+  conv.cv.kh = (int32_t)kh;
+  conv.cv.kw = (int32_t)kw;
+  conv.cv.ph = (int32_t)pad_h;
+  conv.cv.pw = (int32_t)pad_w;
+  conv.cv.Ho = (int32_t)ho;
+  conv.cv.Wo = (int32_t)wo;
+  conv.cv.C_out = (int32_t)out_channels;
+  conv.cv.post_scale = 0.5 * (double)d;
+  qiddm::AdjointScalars ad;
+  ad.gin_ld = c->n_features;
+  ad.want_inputs = grad_x != nullptr ? 1 : 0;
+  ad.pad_ = 0;
+  Ptrs ptr;
+  ptr.table = gate_table;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  rc = c->dtype == QIDDM_F32
+           ? dispatch_adjoint<float, true>(c->n_qubits, ptr, k_partials, grad_features, p, ad, conv, st)
+           : dispatch_adjoint<double, true>(c->n_qubits, ptr, k_partials, grad_features, p, ad, conv, st);
+  if (rc != QIDDM_OK || grad_x == nullptr || batch == 0) return rc;
+  const int64_t total = batch * in_channels * height * width;
+  const unsigned blocks = (unsigned)((total + 255) / 256);
+  if (c->dtype == QIDDM_F32)
+    hipLaunchKernelGGL(qiddm::qconv_fold_kernel<float>, dim3(blocks), dim3(256), 0, st,
+                       static_cast<const float*>(grad_features), grad_x, total, conv.cv);
+  else
+    hipLaunchKernelGGL(qiddm::qconv_fold_kernel<double>, dim3(blocks), dim3(256), 0, st,
+                       static_cast<const double*>(grad_features), grad_x, total, conv.cv);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_fold launch failed: %s", hipGetErrorString(e));
+  return QIDDM_OK;
 }
 
 int qiddm_adjoint_finalize(const qiddm_circuit_t* c, const double* angles, const void* k_partials,

@@ -61,6 +61,29 @@ struct AdjointScalars {
   int32_t pad_;
 };
 
+// where the upstream gradient dL/d(out) of a sample comes from
+template <typename T>
+struct RowGrad {  // a row of a (batch, 2^N | N) matrix
+  const T* __restrict__ row;
+  __device__ __forceinline__ T prob(int k, T) const { return row[k]; }
+  __device__ __forceinline__ T expz(int w) const { return row[w]; }
+};
+// the quantum convolution's post-processing y[co] = clamp(p[2 co] * D/2, 0, 1) (reference nn/qconv.py:58-69)
+// differentiated in place: dL/dp_k is read from the (B, C_out, Ho, Wo) gradient of y at this pixel, for even
+// k < 2 C_out and where the clamp lets it through (torch: min <= value <= max), and is zero elsewhere
+template <typename T>
+struct ConvGrad {
+  const double* __restrict__ gy;  // at (b, 0, oi, oj)
+  int64_t ch_stride;              // Ho * Wo
+  int C_out;
+  T post_scale;                   // D / 2
+  __device__ __forceinline__ T prob(int k, T p2) const {
+    if ((k & 1) != 0 || (k >> 1) >= C_out || p2 * post_scale > (T)1) return (T)0;
+    return (T)gy[(int64_t)(k >> 1) * ch_stride] * post_scale;
+  }
+  __device__ __forceinline__ T expz(int) const { return (T)0; }
+};
+
 template <typename T, int N>
 struct AdjointEngine {
   using E = Engine<T, N>;
@@ -502,11 +525,11 @@ struct AdjointEngine {
   }
 
   // ---- one sample (group): forward, then the reverse sweep ------------------------------------------
-  // g_row: upstream gradient row ((2^N) probabilities or N expectation values).
+  // g_src: upstream gradient of this sample (RowGrad / ConvGrad).
   // gin_row: where this sample's input gradient goes (may be null).
-  template <typename Src>
+  template <typename Src, typename GSrc>
   __device__ __forceinline__ void run(const KScalars& p, const Src& amp_src, T (&xs)[N],
-                                      const T* __restrict__ g_row, T* __restrict__ gin_row, bool valid,
+                                      const GSrc& g_src, T* __restrict__ gin_row, bool valid,
                                       bool folded = false) const {
     const int lane = fwd.lane, sub = fwd.sub;
     C psi[R], dx[R];
@@ -521,13 +544,13 @@ struct AdjointEngine {
     if (p.measure == 0) {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const T g = valid ? g_row[(r << LB) | sub] : (T)0;
+        const T g = valid ? g_src.prob((r << LB) | sub, psi[r].x * psi[r].x + psi[r].y * psi[r].y) : (T)0;
         lam[r] = C{g * psi[r].x, g * psi[r].y};
       }
     } else {
       T gw[N];
 #pragma unroll
-      for (int w = 0; w < N; ++w) gw[w] = valid ? g_row[w] : (T)0;
+      for (int w = 0; w < N; ++w) gw[w] = valid ? g_src.expz(w) : (T)0;
       seed_expz(gw, psi, lam);
     }
     T gx[N];
@@ -566,13 +589,17 @@ struct AdjointEngine {
 // ---------------------------------------------------------------------------
 // kernel: grid-strided over samples; every block writes its K partial slab [n_rot][8]
 // ---------------------------------------------------------------------------
-template <typename T, int N>
+// CONV: the samples are the output pixels of a quantum convolution -- features read from the image through
+// PatchSrc (the unfold never exists), upstream gradient read from dL/dy through ConvGrad; `inputs` / `gout` unused.
+template <typename T, int N, bool CONV>
 __global__ __launch_bounds__(4 * kWave) void adjoint_kernel(const T* __restrict__ inputs,
                                                             const T* __restrict__ table,
                                                             const T* __restrict__ gout,
                                                             T* __restrict__ k_partials,
                                                             T* __restrict__ grad_inputs, const KScalars p,
-                                                            const AdjointScalars ad) {
+                                                            const AdjointScalars ad,
+                                                            const double* __restrict__ img,
+                                                            const double* __restrict__ gy, const ConvScalars cv) {
   using E = Engine<T, N>;
   using L = typename E::L;
   using S = Smem<T, N>;
@@ -626,9 +653,19 @@ __global__ __launch_bounds__(4 * kWave) void adjoint_kernel(const T* __restrict_
     }
     // an out-of-range slot (sub-wave layouts only) repeats the last sample with a zero upstream
     // gradient: it still takes part in the wave-wide exchanges but adds nothing to K
-    const T* g_row = gout + sample * p.g_ld;
     T* gin_row = ad.want_inputs ? grad_inputs + sample * ad.gin_ld : nullptr;
-    adj.run(p, RowSrc<T>{inputs + sample * p.in_ld}, xs, g_row, gin_row, valid, folded);
+    if constexpr (CONV) {
+      const int64_t pixels = (int64_t)cv.Ho * cv.Wo;
+      const int64_t b = sample / pixels;
+      const int pix = (int)(sample - b * pixels);
+      const int oi = pix / cv.Wo, oj = pix - oi * cv.Wo;
+      const PatchSrc<T> src{img + (size_t)b * cv.C * cv.H * cv.W, cv.H, cv.W, cv.kh, cv.kw, oi - cv.ph, oj - cv.pw};
+      const ConvGrad<T> g_src{gy + (size_t)b * cv.C_out * pixels + pix, pixels, cv.C_out, (T)cv.post_scale};
+      adj.run(p, src, xs, g_src, gin_row, valid, folded);
+    } else {
+      adj.run(p, RowSrc<T>{inputs + sample * p.in_ld}, xs, RowGrad<T>{gout + sample * p.g_ld}, gin_row, valid,
+              folded);
+    }
   }
   __syncthreads();
   // block partial: sum the waves' accumulators in a fixed order (deterministic); slab stride n_rot * 8 either way
@@ -637,6 +674,34 @@ __global__ __launch_bounds__(4 * kWave) void adjoint_kernel(const T* __restrict_
     for (int w = 0; w < waves; ++w) tot += kall[(size_t)w * acc_len + i];
     k_partials[(size_t)blockIdx.x * n_rot * 8 + i] = tot;
   }
+}
+
+// dL/dx of the quantum convolution from the per-pixel feature gradients (M = B Ho Wo rows of F = C kh kw):
+// the transpose of torch.nn.Unfold as a gather -- every input element sums the kh*kw patch entries it appeared in,
+// in a fixed order (deterministic; no atomics).
+template <typename T>
+__global__ __launch_bounds__(256) void qconv_fold_kernel(const T* __restrict__ gfeat, double* __restrict__ gx,
+                                                         int64_t total, const ConvScalars cv) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int j = (int)(idx % cv.W);
+  int64_t t = idx / cv.W;
+  const int i = (int)(t % cv.H);
+  t /= cv.H;
+  const int c = (int)(t % cv.C);
+  const int64_t b = t / cv.C;
+  const int F = cv.C * cv.kh * cv.kw;
+  double acc = 0;
+  for (int di = 0; di < cv.kh; ++di) {
+    const int oi = i - di + cv.ph;
+    if (oi < 0 || oi >= cv.Ho) continue;
+    for (int dj = 0; dj < cv.kw; ++dj) {
+      const int oj = j - dj + cv.pw;
+      if (oj < 0 || oj >= cv.Wo) continue;
+      acc += (double)gfeat[((b * cv.Ho + oi) * cv.Wo + oj) * F + (c * cv.kh + di) * cv.kw + dj];
+    }
+  }
+  gx[idx] = acc;
 }
 
 // 2 Re sum_ab (dU/dangle)_ab K_ab for the three angles of one Rot gate (float64); k = K00 K01 K10 K11 as (re, im)

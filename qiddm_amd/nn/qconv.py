@@ -22,6 +22,7 @@ import torch
 from .. import circuit as _c
 from .. import qml
 from .qdense import _qw_tanh
+from .utils import unfold_patches
 
 
 class QConv2d(torch.nn.Module):
@@ -76,8 +77,13 @@ class QConv2d(torch.nn.Module):
             # inference: unfold + embedding + circuit + post-processing in one launch
             return _c.qconv_forward(x, _qw_tanh(self.weights.detach().double()), self.wires,
                                     self.out_channels, self.kernel_size, self.padding)
-        cols = self.unfold(x.double())                                   # (b, C k^2, h_out*w_out)
-        feats = cols.transpose(1, 2).reshape(b * h_out * w_out, -1) + 0.1
+        if (self.qnode is self._own_qnode and self.wires <= 10 and x.is_cuda
+                and 2 * self.out_channels <= 2 ** self.wires):
+            # training: the same fused launch, differentiable (adjoint sweep per output pixel + fold)
+            return _c.qconv_execute(x.double(), _qw_tanh(self.weights.double()), self.wires, self.out_channels,
+                                    self.kernel_size, self.padding)
+        # self.unfold's columns, one row per output pixel (a strided view + one copy; nn/utils.unfold_patches)
+        feats = unfold_patches(x.double(), self.kernel_size, self.padding) + 0.1
         y = self._post_process(self.qnode(feats))                        # ((b h w), C_out)
         return y.reshape(b, h_out, w_out, -1).permute(0, 3, 1, 2).contiguous()
 

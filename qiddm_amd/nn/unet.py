@@ -7,7 +7,8 @@ from __future__ import annotations
 import torch
 
 from .qconv import QConv2d
-from .utils import autopad, get_label_embedding
+from .utils import (autopad, bilinear_upsample2x, get_label_embedding, is_bilinear2x, is_pointwise,
+                    pointwise_conv)
 
 F64 = torch.double
 
@@ -39,8 +40,15 @@ class UpBlock(torch.nn.Module):
             torch.nn.BatchNorm2d(out_channels, dtype=F64), torch.nn.ReLU(),
         ).to(F64)
 
+    def _up(self, x):
+        if len(self.up_conv) == 2 and is_bilinear2x(self.up_conv[0]) and x.is_cuda:
+            x = bilinear_upsample2x(x.to(F64))          # same interpolation weights, as two matrix products
+            conv = self.up_conv[1]
+            return pointwise_conv(conv, x) if is_pointwise(conv) else conv(x)
+        return self.up_conv(x)
+
     def forward(self, from_down, from_up):
-        skip, up = autopad(from_down.to(F64), self.up_conv(from_up).to(F64))
+        skip, up = autopad(from_down.to(F64), self._up(from_up).to(F64))
         return self.net(torch.cat([up, skip], dim=1).to(F64))
 
 
@@ -91,6 +99,8 @@ class UNetUndirected(torch.nn.Module):
             skips.append(before_pool)
         for i, block in enumerate(self.up_blocks):
             x = block(skips[-(i + 2)].to(F64), x.to(F64))
+        if is_pointwise(self.final_conv) and x.is_cuda:
+            return pointwise_conv(self.final_conv, x)
         return self.final_conv(x)
 
     def extra_repr(self) -> str:

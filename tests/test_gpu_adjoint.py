@@ -87,6 +87,43 @@ def test_qconv_stack_trains_through_the_adjoint():
     assert torch.allclose(c1.weights.grad.cpu(), w1.grad, atol=1e-8), (c1.weights.grad.cpu() - w1.grad).abs().max()
 
 
+@pytest.mark.parametrize("c_in,c_out,k,pad,hw,qdepth,precision,tol", [
+    (1, 4, 3, 1, (6, 5), 2, "f64", 1e-9),       # first UNet layer shape: 9 features on 4 wires
+    (8, 16, 3, 1, (7, 7), 3, "f64", 1e-9),      # 72 features on 7 wires, sub-wave layout boundary
+    (16, 8, 1, 0, (4, 6), 2, "f64", 1e-9),      # the 1x1 `up_conv`
+    (3, 2, 3, 0, (6, 6), 1, "f64", 1e-9),       # no padding: H_out < H
+    (16, 16, 3, 1, (8, 8), 3, "f32", 2e-4),     # 144 features on 8 wires, float32 engine
+    (32, 32, 3, 1, (5, 5), 2, "f32", 2e-4),     # 288 features on 9 wires
+])
+def test_fused_qconv_backward_vs_oracle_autograd(c_in, c_out, k, pad, hw, qdepth, precision, tol):
+    """qiddm_qconv_backward (adjoint sweep with the patch and dL/dy read in place, then the fold): d/dweights and
+    d/dx of QConv2d against torch autograd through the oracle's unfold / circuit / clamp / slices."""
+    from qiddm_amd import nn, set_default_precision
+    torch.manual_seed(11)
+    layer = nn.QConv2d(c_in, c_out, k, pad, qdepth).cuda().train()
+    x = torch.rand(2, c_in, *hw, dtype=torch.float64)
+    x[0, :, 0, 0] = 0.0
+    gy = torch.randn(2, c_out, hw[0] + 2 * pad - k + 1, hw[1] + 2 * pad - k + 1, dtype=torch.float64)
+    xg = x.cuda().requires_grad_(True)
+    set_default_precision(precision)
+    try:
+        y = layer(xg)
+        (y * gy.cuda()).sum().backward()
+    finally:
+        set_default_precision("f32")
+    xo = x.clone().requires_grad_(True)
+    wo = layer.weights.detach().cpu().clone().requires_grad_(True)
+    yo = oc.qconv2d_forward(xo, wo, c_out, (k, k), (pad, pad))
+    (yo * gy).sum().backward()
+    assert y.shape == yo.shape
+    assert torch.allclose(y.detach().cpu(), yo.detach(), atol=tol * 10)
+    scale = max(1.0, wo.grad.abs().max().item())
+    assert torch.allclose(layer.weights.grad.cpu(), wo.grad, atol=tol * scale * 10), \
+        (layer.weights.grad.cpu() - wo.grad).abs().max()
+    sx = max(1.0, xo.grad.abs().max().item())
+    assert torch.allclose(xg.grad.cpu(), xo.grad, atol=tol * sx * 10), (xg.grad.cpu() - xo.grad).abs().max()
+
+
 def test_differn_backprop_training_step():
     """differN (diff_method='backprop') end to end: chained rounds, grads == oracle autograd."""
     from qiddm_amd import nn, set_default_precision
