@@ -57,7 +57,13 @@ def unfold_patches(x: torch.Tensor, kernel_size, padding) -> torch.Tensor:
 
 def pointwise_conv(conv: torch.nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     """A 1x1, stride-1, ungrouped ``Conv2d`` as one matrix product over the channel axis."""
-    y = torch.einsum("bchw,oc->bohw", x, conv.weight[:, :, 0, 0])
+    w = conv.weight[:, :, 0, 0]
+    if w.shape[0] == 1:
+        # one output channel (the UNets' head): a weighted channel sum -- its weight gradient is then a plain
+        # reduction instead of a (1 x C) product over B*H*W terms, which the BLAS handles badly
+        y = (x * w.view(1, -1, 1, 1)).sum(dim=1, keepdim=True)
+    else:
+        y = torch.einsum("bchw,oc->bohw", x, w)
     return y if conv.bias is None else y + conv.bias.view(1, -1, 1, 1)
 
 

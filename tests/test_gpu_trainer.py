@@ -44,6 +44,38 @@ def test_graphed_step_matches_eager(detach, method):
         assert not torch.equal(rec.net.weights, _make(detach, method).net.weights)   # the angles trained
 
 
+def test_graphed_unet_simple_step_matches_eager():
+    """The unet_simple training step (fused QConv2d forward / adjoint backward launches, BatchNorm in training mode,
+    matrix-product glue) records into HIP graphs and replays to the eager numbers, BatchNorm statistics included."""
+    from qiddm_amd import models, nn, noise
+    from qiddm_amd.optim import FusedAdam
+    from qiddm_amd.trainer import GraphedTrainStep
+
+    def make():
+        torch.manual_seed(3)
+        net = nn.UNetUndirectedS(2, 4, 2)
+        return models.Diffusion(net, noise.add_normal_noise_multiple, "data", (8, 8),
+                                torch.nn.MSELoss()).to("cuda", dtype=torch.double).train()
+
+    xs = [torch.rand(3, 64, dtype=torch.double, device="cuda") for _ in range(3)]
+    eager = make()
+    opt_e = torch.optim.Adam(eager.parameters(), lr=1e-2)
+    torch.manual_seed(123)
+    losses_e = []
+    for x in xs:
+        opt_e.zero_grad()
+        (loss,) = eager(x=x, T=4)
+        opt_e.step()
+        losses_e.append(loss.item())
+    rec = make()
+    step = GraphedTrainStep(rec, FusedAdam(rec.parameters(), lr=1e-2), xs[0], T=4, noise="reference")
+    torch.manual_seed(123)
+    losses_r = [step(x)[0].item() for x in xs]
+    assert losses_r == pytest.approx(losses_e, rel=1e-6, abs=1e-9)
+    for (k, a), (_, b) in zip(eager.state_dict().items(), rec.state_dict().items()):
+        assert torch.allclose(a.double(), b.double(), rtol=1e-5, atol=1e-7), k
+
+
 def test_device_noise_and_shape_check():
     from qiddm_amd.trainer import GraphedTrainStep
     diff = _make(True, "parameter-shift")
