@@ -360,6 +360,24 @@ int qiddm_qconv_unitary_forward(int32_t n_qubits, const double *u, const double 
                                 const qiddm_batchnorm_t *bn, int32_t u_transposed, double *y, void *workspace,
                                 int64_t workspace_bytes, void *stream);
 
+/* ---- training-mode BatchNorm2d, float64 NCHW ------------------------------------------------------------
+ * The `torch.nn.BatchNorm2d` behind every quantum convolution of `unet_simple` (reference
+ * nn/unet_simple.py:9-18, 30-39) in training mode: per-channel batch statistics (biased variance for the
+ * transform, unbiased for the running estimate), running_mean / running_var moved by `momentum` in place
+ * (either may be NULL), y = (x - mean) / sqrt(var + eps) * weight + bias (weight / bias may be NULL).
+ * save_mean / save_invstd (channels) feed the backward: grad_x (may be NULL), grad_weight, grad_bias (may be
+ * NULL).  x: (batch, channels, hw).  Two launches per direction, sums in a fixed order (deterministic).
+ * workspace: qiddm_batchnorm_workspace_bytes, rewritten by every call.                                     */
+int64_t qiddm_batchnorm_workspace_bytes(int64_t batch, int64_t channels, int64_t hw);
+int qiddm_batchnorm_train_forward(const double *x, int64_t batch, int64_t channels, int64_t hw,
+                                  const double *weight, const double *bias, double *running_mean,
+                                  double *running_var, double momentum, double eps, double *y, double *save_mean,
+                                  double *save_invstd, void *workspace, int64_t workspace_bytes, void *stream);
+int qiddm_batchnorm_backward(const double *x, const double *grad_y, int64_t batch, int64_t channels, int64_t hw,
+                             const double *weight, const double *save_mean, const double *save_invstd,
+                             double *grad_x, double *grad_weight, double *grad_bias, void *workspace,
+                             int64_t workspace_bytes, void *stream);
+
 /* classical 1x1 convolution, float64 NCHW (the UNets' `final_conv`, reference nn/unet.py:160-166):
  * x (batch, in_channels, hw), weight (out_channels, in_channels), bias (out_channels) or NULL.          */
 int qiddm_conv1x1_forward(const double *x, const double *weight, const double *bias, int64_t batch,

@@ -57,6 +57,9 @@ EXPORTS = (
     "qiddm_qconv_unitary_workspace_bytes",
     "qiddm_qconv_unitary_forward",
     "qiddm_conv1x1_forward",
+    "qiddm_batchnorm_workspace_bytes",
+    "qiddm_batchnorm_train_forward",
+    "qiddm_batchnorm_backward",
     "qiddm_mixed_workspace_bytes",
     "qiddm_mixed_forward",
 )
@@ -138,6 +141,13 @@ def _declare(lib):
     lib.qiddm_qconv_forward.argtypes = [P, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, vp, vp]
     lib.qiddm_qconv_backward.restype = ctypes.c_int
     lib.qiddm_qconv_backward.argtypes = [P, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, vp, i64, vp, vp, vp, vp]
+    dbl = ctypes.c_double
+    lib.qiddm_batchnorm_workspace_bytes.restype = ctypes.c_int64
+    lib.qiddm_batchnorm_workspace_bytes.argtypes = [i64, i64, i64]
+    lib.qiddm_batchnorm_train_forward.restype = ctypes.c_int
+    lib.qiddm_batchnorm_train_forward.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, dbl, dbl, vp, vp, vp, vp, i64, vp]
+    lib.qiddm_batchnorm_backward.restype = ctypes.c_int
+    lib.qiddm_batchnorm_backward.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.qiddm_train_workspace_bytes.restype = ctypes.c_int64
     lib.qiddm_train_workspace_bytes.argtypes = [P, i64, ctypes.c_int32, ctypes.c_int32]
     lib.qiddm_train_step.restype = ctypes.c_int

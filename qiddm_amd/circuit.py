@@ -549,6 +549,78 @@ def qconv_execute(x: torch.Tensor, angles: torch.Tensor, n_qubits: int, out_chan
                                 precision or _default_precision)
 
 
+def _norm_workspace(batch, channels, hw, device):
+    need = _capi.lib().qiddm_batchnorm_workspace_bytes(batch, channels, hw)
+    if need < 0:
+        _capi.check(-1)
+    key = ("norm", device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _workspaces[key] = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=device)
+    return ws
+
+
+class _BatchNormTrainFunction(torch.autograd.Function):
+    """Training-mode ``BatchNorm2d`` in float64 (``qiddm_batchnorm_train_forward`` / ``_backward``); moves the
+    running statistics in place like the torch module."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        b, c = x.shape[:2]
+        hw = x.numel() // max(b * c, 1)
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        mean = torch.empty(c, dtype=torch.float64, device=x.device)
+        invstd = torch.empty_like(mean)
+        ws = _norm_workspace(b, c, hw, x.device)
+
+        def ptr(t):
+            return 0 if t is None else t.data_ptr()
+
+        _capi.check(_capi.lib().qiddm_batchnorm_train_forward(
+            x.data_ptr(), b, c, hw, ptr(weight), ptr(bias), ptr(running_mean), ptr(running_var), float(momentum),
+            float(eps), y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(),
+            _stream_ptr(x.device)))
+        ctx.save_for_backward(x, weight, mean, invstd)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, mean, invstd = ctx.saved_tensors
+        b, c = x.shape[:2]
+        hw = x.numel() // max(b * c, 1)
+        gy = gy.contiguous()
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gw = torch.empty(c, dtype=torch.float64, device=x.device) if weight is not None else None
+        gb = torch.empty(c, dtype=torch.float64, device=x.device) if ctx.has_bias else None
+        ws = _norm_workspace(b, c, hw, x.device)
+
+        def ptr(t):
+            return 0 if t is None else t.data_ptr()
+
+        _capi.check(_capi.lib().qiddm_batchnorm_backward(
+            x.data_ptr(), gy.data_ptr(), b, c, hw, ptr(weight), mean.data_ptr(), invstd.data_ptr(), ptr(gx), ptr(gw),
+            ptr(gb), ws.data_ptr(), ws.numel(), _stream_ptr(x.device)))
+        return gx, gw, gb, None, None, None, None
+
+
+def batch_norm_train(bn: torch.nn.BatchNorm2d, x: torch.Tensor) -> torch.Tensor:
+    """``bn(x)`` for a float64 ``BatchNorm2d`` in training mode on the device, through the HIP kernels; anything else
+    (eval mode, cumulative-average momentum, other dtypes, empty batches, CPU) goes to the torch module."""
+    if not (bn.training and x.is_cuda and x.dtype == torch.float64 and x.dim() == 4 and x.numel() > 0
+            and bn.momentum is not None and (bn.weight is None or bn.weight.dtype == torch.float64)
+            and (bn.running_mean is None or bn.running_mean.dtype == torch.float64)):
+        return bn(x)
+    if x.shape[1] != bn.num_features:
+        return bn(x)       # torch raises its own message
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _BatchNormTrainFunction.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps)
+
+
 def run_shift_sweep(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch.Tensor,
                     precision: str | None = None, with_inputs: bool = True,
                     max_dots_elems: int = 1 << 26):

@@ -1,0 +1,249 @@
+// C ABI of the training-mode BatchNorm2d that follows every quantum convolution of `unet_simple`
+// (reference nn/unet_simple.py:9-18, 30-39: `net = [QConv2d, BatchNorm2d]`).
+//
+// torch has no float64 library path for it on ROCm and runs three generic launches forward (statistics,
+// running-stat update, transform) and a slow one backward; here each direction is two launches over a
+// (channel, batch-slice) grid: partial sums, then every workgroup re-reduces its channel's partials in a fixed
+// order (deterministic, no atomics) and transforms its slice.
+#include "capi_common.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+using qiddm_capi::fail;
+
+namespace qiddm {
+
+constexpr int kNormThreads = 256;
+constexpr int kNormMaxSlices = 64;
+
+struct NormGeom {
+  int64_t batch, hw;
+  int32_t channels, slices;
+};
+
+__device__ __forceinline__ double block_sum(double v, double* s_red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  double t = 0;
+  for (int w = 0; w < kNormThreads / 64; ++w) t += s_red[w];
+  return t;
+}
+
+// batch rows [b0, b1) of slice s
+__device__ __forceinline__ void slice_range(const NormGeom& g, int s, int64_t& b0, int64_t& b1) {
+  b0 = g.batch * s / g.slices;
+  b1 = g.batch * (s + 1) / g.slices;
+}
+
+// forward pass 1: per (channel, slice) sums of d = x - pivot and d^2, pivot = the channel's first element
+// (keeps the variance free of the E[x^2] - E[x]^2 cancellation)
+__global__ __launch_bounds__(kNormThreads) void bn_stats_kernel(const double* __restrict__ x, const NormGeom g,
+                                                                double* __restrict__ partial) {
+  __shared__ double s_red[kNormThreads / 64];
+  const int c = blockIdx.x, s = blockIdx.y;
+  int64_t b0, b1;
+  slice_range(g, s, b0, b1);
+  const double pivot = x[(int64_t)c * g.hw];
+  double sum = 0, sq = 0;
+  for (int64_t b = b0; b < b1; ++b) {
+    const double* row = x + (b * g.channels + c) * g.hw;
+    for (int64_t i = threadIdx.x; i < g.hw; i += kNormThreads) {
+      const double d = row[i] - pivot;
+      sum += d;
+      sq = fma(d, d, sq);
+    }
+  }
+  sum = block_sum(sum, s_red);
+  sq = block_sum(sq, s_red);
+  if (threadIdx.x == 0) {
+    partial[((int64_t)c * g.slices + s) * 2 + 0] = sum;
+    partial[((int64_t)c * g.slices + s) * 2 + 1] = sq;
+  }
+}
+
+// forward pass 2: y = (x - mean) * invstd * weight + bias; slice 0 of a channel also stores mean / invstd and
+// moves the running statistics (unbiased variance, as torch does)
+__global__ __launch_bounds__(kNormThreads) void bn_apply_kernel(const double* __restrict__ x, const NormGeom g,
+                                                                const double* __restrict__ partial,
+                                                                const double* __restrict__ weight,
+                                                                const double* __restrict__ bias,
+                                                                double* __restrict__ running_mean,
+                                                                double* __restrict__ running_var, double momentum,
+                                                                double eps, double* __restrict__ y,
+                                                                double* __restrict__ save_mean,
+                                                                double* __restrict__ save_invstd) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  double sum = 0, sq = 0;
+  for (int i = 0; i < g.slices; ++i) {
+    sum += partial[((int64_t)c * g.slices + i) * 2 + 0];
+    sq += partial[((int64_t)c * g.slices + i) * 2 + 1];
+  }
+  const double n = (double)(g.batch * g.hw);
+  const double pivot = x[(int64_t)c * g.hw];
+  const double dmean = sum / n;
+  const double mean = pivot + dmean;
+  double var = (sq - sum * dmean) / n;
+  var = var < 0 ? 0 : var;
+  const double invstd = 1.0 / sqrt(var + eps);
+  if (s == 0 && threadIdx.x == 0) {
+    save_mean[c] = mean;
+    save_invstd[c] = invstd;
+    if (running_mean) running_mean[c] = (1.0 - momentum) * running_mean[c] + momentum * mean;
+    if (running_var) {
+      const double unbiased = n > 1 ? var * n / (n - 1.0) : var;
+      running_var[c] = (1.0 - momentum) * running_var[c] + momentum * unbiased;
+    }
+  }
+  const double scale = invstd * (weight ? weight[c] : 1.0);
+  const double shift = bias ? bias[c] : 0.0;
+  int64_t b0, b1;
+  slice_range(g, s, b0, b1);
+  for (int64_t b = b0; b < b1; ++b) {
+    const int64_t base = (b * g.channels + c) * g.hw;
+    for (int64_t i = threadIdx.x; i < g.hw; i += kNormThreads) y[base + i] = fma(x[base + i] - mean, scale, shift);
+  }
+}
+
+// backward pass 1: per (channel, slice) sums of g and g * xhat
+__global__ __launch_bounds__(kNormThreads) void bn_back_stats_kernel(const double* __restrict__ x,
+                                                                     const double* __restrict__ gy, const NormGeom g,
+                                                                     const double* __restrict__ save_mean,
+                                                                     const double* __restrict__ save_invstd,
+                                                                     double* __restrict__ partial) {
+  __shared__ double s_red[kNormThreads / 64];
+  const int c = blockIdx.x, s = blockIdx.y;
+  int64_t b0, b1;
+  slice_range(g, s, b0, b1);
+  const double mean = save_mean[c], invstd = save_invstd[c];
+  double sg = 0, sgx = 0;
+  for (int64_t b = b0; b < b1; ++b) {
+    const int64_t base = (b * g.channels + c) * g.hw;
+    for (int64_t i = threadIdx.x; i < g.hw; i += kNormThreads) {
+      const double gv = gy[base + i];
+      sg += gv;
+      sgx = fma(gv, (x[base + i] - mean) * invstd, sgx);
+    }
+  }
+  sg = block_sum(sg, s_red);
+  sgx = block_sum(sgx, s_red);
+  if (threadIdx.x == 0) {
+    partial[((int64_t)c * g.slices + s) * 2 + 0] = sg;
+    partial[((int64_t)c * g.slices + s) * 2 + 1] = sgx;
+  }
+}
+
+// backward pass 2: dx = weight * invstd * (g - mean(g) - xhat * mean(g * xhat)); dweight = sum g xhat, dbias = sum g
+__global__ __launch_bounds__(kNormThreads) void bn_back_apply_kernel(const double* __restrict__ x,
+                                                                     const double* __restrict__ gy, const NormGeom g,
+                                                                     const double* __restrict__ partial,
+                                                                     const double* __restrict__ weight,
+                                                                     const double* __restrict__ save_mean,
+                                                                     const double* __restrict__ save_invstd,
+                                                                     double* __restrict__ gx,
+                                                                     double* __restrict__ gweight,
+                                                                     double* __restrict__ gbias) {
+  const int c = blockIdx.x, s = blockIdx.y;
+  double sg = 0, sgx = 0;
+  for (int i = 0; i < g.slices; ++i) {
+    sg += partial[((int64_t)c * g.slices + i) * 2 + 0];
+    sgx += partial[((int64_t)c * g.slices + i) * 2 + 1];
+  }
+  if (s == 0 && threadIdx.x == 0) {
+    if (gweight) gweight[c] = sgx;
+    if (gbias) gbias[c] = sg;
+  }
+  if (!gx) return;
+  const double n = (double)(g.batch * g.hw);
+  const double mean = save_mean[c], invstd = save_invstd[c];
+  const double k = invstd * (weight ? weight[c] : 1.0);
+  const double mg = sg / n, mgx = sgx / n;
+  int64_t b0, b1;
+  slice_range(g, s, b0, b1);
+  for (int64_t b = b0; b < b1; ++b) {
+    const int64_t base = (b * g.channels + c) * g.hw;
+    for (int64_t i = threadIdx.x; i < g.hw; i += kNormThreads) {
+      const double xh = (x[base + i] - mean) * invstd;
+      gx[base + i] = k * (gy[base + i] - mg - xh * mgx);
+    }
+  }
+}
+
+}  // namespace qiddm
+
+namespace {
+
+int make_geom(int64_t batch, int64_t channels, int64_t hw, qiddm::NormGeom* g) {
+  if (batch < 1 || channels < 1 || hw < 1) return fail(QIDDM_ERR_INVALID, "BatchNorm needs batch, channels, hw >= 1");
+  if (channels > 65535 || batch * channels * hw >= ((int64_t)1 << 40))
+    return fail(QIDDM_ERR_UNSUPPORTED, "BatchNorm tensor too large for one launch");
+  g->batch = batch;
+  g->hw = hw;
+  g->channels = (int32_t)channels;
+  g->slices = (int32_t)(batch < qiddm::kNormMaxSlices ? batch : qiddm::kNormMaxSlices);
+  return QIDDM_OK;
+}
+
+int launched(const char* what) {
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "%s launch failed: %s", what, hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t qiddm_batchnorm_workspace_bytes(int64_t batch, int64_t channels, int64_t hw) {
+  qiddm::NormGeom g;
+  if (make_geom(batch, channels, hw, &g) != QIDDM_OK) return -1;
+  return (int64_t)g.channels * g.slices * 2 * (int64_t)sizeof(double);
+}
+
+int qiddm_batchnorm_train_forward(const double* x, int64_t batch, int64_t channels, int64_t hw,
+                                  const double* weight, const double* bias, double* running_mean,
+                                  double* running_var, double momentum, double eps, double* y, double* save_mean,
+                                  double* save_invstd, void* workspace, int64_t workspace_bytes, void* stream) {
+  qiddm::NormGeom g;
+  const int rc = make_geom(batch, channels, hw, &g);
+  if (rc != QIDDM_OK) return rc;
+  if (!x || !y || !save_mean || !save_invstd || !workspace)
+    return fail(QIDDM_ERR_INVALID, "x/y/save_mean/save_invstd/workspace is NULL");
+  if (workspace_bytes < qiddm_batchnorm_workspace_bytes(batch, channels, hw))
+    return fail(QIDDM_ERR_INVALID, "workspace too small");
+  if (!(eps >= 0.0)) return fail(QIDDM_ERR_INVALID, "eps < 0");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double* partial = static_cast<double*>(workspace);
+  const dim3 grid((unsigned)g.channels, (unsigned)g.slices);
+  hipLaunchKernelGGL(qiddm::bn_stats_kernel, grid, dim3(qiddm::kNormThreads), 0, st, x, g, partial);
+  hipLaunchKernelGGL(qiddm::bn_apply_kernel, grid, dim3(qiddm::kNormThreads), 0, st, x, g, partial, weight, bias,
+                     running_mean, running_var, momentum, eps, y, save_mean, save_invstd);
+  return launched("bn_apply_kernel");
+}
+
+int qiddm_batchnorm_backward(const double* x, const double* grad_y, int64_t batch, int64_t channels, int64_t hw,
+                             const double* weight, const double* save_mean, const double* save_invstd,
+                             double* grad_x, double* grad_weight, double* grad_bias, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+  qiddm::NormGeom g;
+  const int rc = make_geom(batch, channels, hw, &g);
+  if (rc != QIDDM_OK) return rc;
+  if (!x || !grad_y || !save_mean || !save_invstd || !workspace)
+    return fail(QIDDM_ERR_INVALID, "x/grad_y/save_mean/save_invstd/workspace is NULL");
+  if (workspace_bytes < qiddm_batchnorm_workspace_bytes(batch, channels, hw))
+    return fail(QIDDM_ERR_INVALID, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double* partial = static_cast<double*>(workspace);
+  const dim3 grid((unsigned)g.channels, (unsigned)g.slices);
+  hipLaunchKernelGGL(qiddm::bn_back_stats_kernel, grid, dim3(qiddm::kNormThreads), 0, st, x, grad_y, g, save_mean,
+                     save_invstd, partial);
+  hipLaunchKernelGGL(qiddm::bn_back_apply_kernel, grid, dim3(qiddm::kNormThreads), 0, st, x, grad_y, g, partial,
+                     weight, save_mean, save_invstd, grad_x, grad_weight, grad_bias);
+  return launched("bn_back_apply_kernel");
+}
+
+}  // extern "C"

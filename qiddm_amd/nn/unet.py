@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import torch
 
+from .. import circuit as _c
 from .qconv import QConv2d
 from .utils import (autopad, bilinear_upsample2x, get_label_embedding, is_bilinear2x, is_pointwise,
                     pointwise_conv)
@@ -22,6 +23,14 @@ def Conv2d(**kwargs):
 
 def _conv3(c_in, c_out, k, qdepth):
     return Conv2d(in_channels=c_in, out_channels=c_out, kernel_size=k, padding=1, qdepth=qdepth)
+
+
+def _run(net: torch.nn.Sequential, x):
+    """``net(x)`` with training-mode float64 BatchNorm2d layers on the HIP kernels (same numbers, same running
+    statistics; torch's float64 batch norm is several generic launches per direction)."""
+    for m in net:
+        x = _c.batch_norm_train(m, x) if type(m) is torch.nn.BatchNorm2d else m(x)
+    return x
 
 
 class UpBlock(torch.nn.Module):
@@ -49,7 +58,7 @@ class UpBlock(torch.nn.Module):
 
     def forward(self, from_down, from_up):
         skip, up = autopad(from_down.to(F64), self._up(from_up).to(F64))
-        return self.net(torch.cat([up, skip], dim=1).to(F64))
+        return _run(self.net, torch.cat([up, skip], dim=1).to(F64))
 
 
 class DownBlock(torch.nn.Module):
@@ -70,7 +79,7 @@ class DownBlock(torch.nn.Module):
             self.pooling_layer = torch.nn.MaxPool2d(kernel_size=2, stride=2)
 
     def forward(self, x):
-        before_pool = self.net(x.to(F64))
+        before_pool = _run(self.net, x.to(F64))
         return (self.pooling_layer(before_pool) if self.pooling else before_pool), before_pool
 
 

@@ -355,3 +355,36 @@ def test_diffusion_sample_uses_fused_steps():
         ref = st[:, :, 0].permute(0, 2, 1, 3).reshape(5 * 28, 6 * 28)
         assert mosaic.shape == ref.shape
         assert torch.allclose(mosaic, ref, atol=1e-4), (goal, (mosaic - ref).abs().max())
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 5, 7), (6, 8, 28, 28), (70, 4, 14, 14), (130, 2, 3, 3)])
+def test_hip_batchnorm_training_matches_torch(shape):
+    """qiddm_batchnorm_train_forward / _backward vs torch.nn.BatchNorm2d (training mode, float64): output, running
+    statistics, num_batches_tracked and all three gradients over two steps; batch counts on either side of the
+    64-slice grid and planes smaller / larger than a workgroup."""
+    from qiddm_amd.circuit import batch_norm_train
+    torch.manual_seed(2)
+    ref = torch.nn.BatchNorm2d(shape[1], dtype=torch.float64).cuda().train()
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5)
+        ref.bias.uniform_(-0.5, 0.5)
+    mine = torch.nn.BatchNorm2d(shape[1], dtype=torch.float64).cuda().train()
+    mine.load_state_dict(ref.state_dict())
+    for step in range(2):
+        x = (torch.rand(*shape, dtype=torch.float64, device="cuda") * 3 + 10.0)     # mean >> std: cancellation check
+        g = torch.randn(*shape, dtype=torch.float64, device="cuda")
+        xa = x.clone().requires_grad_(True)
+        xb = x.clone().requires_grad_(True)
+        ya = ref(xa)
+        yb = batch_norm_train(mine, xb)
+        (ya * g).sum().backward()
+        (yb * g).sum().backward()
+        assert torch.allclose(ya, yb, rtol=1e-11, atol=1e-11), (ya - yb).abs().max()
+        assert torch.allclose(xa.grad, xb.grad, rtol=1e-9, atol=1e-10), (xa.grad - xb.grad).abs().max()
+        assert torch.allclose(ref.weight.grad, mine.weight.grad, rtol=1e-10, atol=1e-10)
+        assert torch.allclose(ref.bias.grad, mine.bias.grad, rtol=1e-10, atol=1e-10)
+    for (k, a), (_, b) in zip(ref.state_dict().items(), mine.state_dict().items()):
+        assert torch.allclose(a.double(), b.double(), rtol=1e-11, atol=1e-12), k
+    # eval mode and float32 stay with torch
+    mine.eval()
+    assert torch.equal(batch_norm_train(mine, x), mine(x))
