@@ -378,6 +378,33 @@ int qiddm_batchnorm_backward(const double *x, const double *grad_y, int64_t batc
                              double *grad_x, double *grad_weight, double *grad_bias, void *workspace,
                              int64_t workspace_bytes, void *stream);
 
+/* ---- quantum convolution backward through the circuit unitary (training) ----------------------------------
+ * The circuit of QConv2d does not depend on the data (reference nn/qconv.py:51-56), so with U = U(weights):
+ * a_mc = sum_j U[2c,j] v^_mj, y_mc = clamp(|a_mc|^2 D/2) for every output pixel m -- and the backward needs no
+ * per-pixel circuit sweep:  with t_mc = dL/dy_mc D/2 where the clamp passes,
+ *     dL/dv^_mj = 2 Re sum_c t_mc conj(a_mc) U[2c,j]   -> through the normalisation and the fold -> grad_x
+ *     dL/dangle = 2 Re sum_c <e_2c| dU/dangle |h_c>,   h_c[j] = sum_m t_mc conj(a_mc) v^_mj
+ * qiddm_qconv_train_backward computes a, dL/dv (stored transposed, (C kh kw, M) float32, then folded into grad_x
+ * unless NULL) and per-workgroup partial sums of h:  h_partials (qiddm_qconv_train_partials, 2 row_channels,
+ * C kh kw + 1) float32 with  h_c[j] = sum_p hp[p][c][j] - i sum_p hp[p][row_channels + c][j];  column C kh kw is the
+ * value every pad column j >= C kh kw shares.
+ *   rows: (C kh kw + 1, 2 row_channels) float32 -- rows[j][c] = Re U[2c,j], rows[j][row_channels + c] = Im U[2c,j],
+ *         last row 0.5 sum_{j >= C kh kw} U[2c,j]; zero for c >= out_channels.  row_channels in {8, 16, 32}
+ *         (C kh kw <= 510; <= 254 for 32): wider layers return QIDDM_ERR_UNSUPPORTED (use qiddm_qconv_backward).
+ * qiddm_matrix_adjoint: K slabs (-> qiddm_adjoint_finalize) of 2 Re <lambda_s| dU/dangle |psi0_s> summed over
+ * `count` (psi0, lambda) pairs of complex128 vectors (count, 2^n, interleaved); circ->dtype QIDDM_F64, gate table
+ * of that dtype, 2 <= n_qubits <= 16.                                                                        */
+int64_t qiddm_qconv_train_partials(int64_t batch, int64_t height_out, int64_t width_out);
+int qiddm_qconv_train_backward(int32_t n_qubits, const double *x, int64_t batch, int64_t in_channels,
+                               int64_t height, int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
+                               const double *grad_y, int64_t out_channels, const float *rows, int32_t row_channels,
+                               float *grad_features_t, float *h_partials, double *grad_x, void *stream);
+int64_t qiddm_matrix_adjoint_partials(int64_t count);
+int64_t qiddm_matrix_adjoint_workspace_bytes(const qiddm_circuit_t *circ, int64_t count);
+int qiddm_matrix_adjoint(const qiddm_circuit_t *circ, const double *psi0, const double *lambda, int64_t count,
+                         const void *gate_table, void *k_partials, void *workspace, int64_t workspace_bytes,
+                         void *stream);
+
 /* classical 1x1 convolution, float64 NCHW (the UNets' `final_conv`, reference nn/unet.py:160-166):
  * x (batch, in_channels, hw), weight (out_channels, in_channels), bias (out_channels) or NULL.          */
 int qiddm_conv1x1_forward(const double *x, const double *weight, const double *bias, int64_t batch,

@@ -57,6 +57,11 @@ EXPORTS = (
     "qiddm_qconv_unitary_workspace_bytes",
     "qiddm_qconv_unitary_forward",
     "qiddm_conv1x1_forward",
+    "qiddm_qconv_train_partials",
+    "qiddm_qconv_train_backward",
+    "qiddm_matrix_adjoint_partials",
+    "qiddm_matrix_adjoint_workspace_bytes",
+    "qiddm_matrix_adjoint",
     "qiddm_batchnorm_workspace_bytes",
     "qiddm_batchnorm_train_forward",
     "qiddm_batchnorm_backward",
@@ -142,6 +147,17 @@ def _declare(lib):
     lib.qiddm_qconv_backward.restype = ctypes.c_int
     lib.qiddm_qconv_backward.argtypes = [P, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, vp, i64, vp, vp, vp, vp]
     dbl = ctypes.c_double
+    lib.qiddm_qconv_train_partials.restype = ctypes.c_int64
+    lib.qiddm_qconv_train_partials.argtypes = [i64, i64, i64]
+    lib.qiddm_qconv_train_backward.restype = ctypes.c_int
+    lib.qiddm_qconv_train_backward.argtypes = [ctypes.c_int32, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, vp,
+                                               ctypes.c_int32, vp, vp, vp, vp]
+    lib.qiddm_matrix_adjoint_partials.restype = ctypes.c_int64
+    lib.qiddm_matrix_adjoint_partials.argtypes = [i64]
+    lib.qiddm_matrix_adjoint_workspace_bytes.restype = ctypes.c_int64
+    lib.qiddm_matrix_adjoint_workspace_bytes.argtypes = [P, i64]
+    lib.qiddm_matrix_adjoint.restype = ctypes.c_int
+    lib.qiddm_matrix_adjoint.argtypes = [P, vp, vp, i64, vp, vp, vp, i64, vp]
     lib.qiddm_batchnorm_workspace_bytes.restype = ctypes.c_int64
     lib.qiddm_batchnorm_workspace_bytes.argtypes = [i64, i64, i64]
     lib.qiddm_batchnorm_train_forward.restype = ctypes.c_int

@@ -549,6 +549,102 @@ def qconv_execute(x: torch.Tensor, angles: torch.Tensor, n_qubits: int, out_chan
                                 precision or _default_precision)
 
 
+def _row_channels(out_channels: int):
+    for co in (8, 16, 32):
+        if out_channels <= co:
+            return co
+    return None
+
+
+def qconv_unitary_trainable(n_qubits: int, in_channels: int, kernel_size, out_channels: int) -> bool:
+    """Whether the unitary-route backward (``qiddm_qconv_train_backward``) covers this layer."""
+    co = _row_channels(out_channels)
+    f = in_channels * kernel_size[0] * kernel_size[1]
+    if co is None or not 2 <= n_qubits <= 12 or 2 * out_channels > 2 ** n_qubits or f > 2 ** n_qubits:
+        return False
+    if max(kernel_size) > 15 or f + 1 > (512 if co <= 16 else 256):
+        return False
+    v_stride = (f + 1) | 1
+    lds = ((f + 1) * 2 * co + 64 * v_stride + 64 * (2 * co + 1)) * 4 + f * 4
+    return lds <= 160 * 1024
+
+
+class _QConvUnitaryFunction(torch.autograd.Function):
+    """QConv2d for training through the circuit's unitary: forward = unitary + the matrix-core GEMM of the eval
+    route; backward = two more thin products per pixel tile and ONE adjoint sweep per output channel
+    (``qiddm_qconv_train_backward`` + ``qiddm_matrix_adjoint``) instead of one sweep per output pixel."""
+
+    @staticmethod
+    def forward(ctx, x, angles, n_qubits, out_channels, kernel_size, padding):
+        u = circuit_unitary(angles.detach(), n_qubits, "CNOT")
+        y = qconv_unitary_forward(x, u, n_qubits, out_channels, kernel_size, padding)
+        ctx.save_for_backward(x, angles, u[0:2 * out_channels:2, :].contiguous())
+        ctx.cfg = (n_qubits, out_channels, kernel_size, padding)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, angles, rows = ctx.saved_tensors
+        n_qubits, c_out, (kh, kw), (ph, pw) = ctx.cfg
+        device = x.device
+        b, c, h, w = x.shape
+        f, d = c * kh * kw, 1 << n_qubits
+        ho, wo = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+        m = b * ho * wo
+        co = _row_channels(c_out)
+        lib = _capi.lib()
+        # rows of U the outputs read: (F + 1, 2 CO) float32, last row = what the 0.5-valued pad columns add up to
+        rt = torch.zeros(f + 1, 2 * co, dtype=torch.float32, device=device)
+        rt[:f, :c_out] = rows.real[:, :f].t()
+        rt[:f, co:co + c_out] = rows.imag[:, :f].t()
+        pad_sum = 0.5 * rows[:, f:].sum(dim=1)
+        rt[f, :c_out] = pad_sum.real
+        rt[f, co:co + c_out] = pad_sum.imag
+        xx = _as_f64(x, device).contiguous()
+        gy = _as_f64(grad_y, device).contiguous()
+        n_part = lib.qiddm_qconv_train_partials(b, ho, wo)
+        gfeat_t = torch.empty(f, m, dtype=torch.float32, device=device)
+        hpart = torch.empty(n_part, 2 * co, f + 1, dtype=torch.float32, device=device)
+        gx = torch.empty(b, c, h, w, dtype=torch.float64, device=device) if ctx.needs_input_grad[0] else None
+        _capi.check(lib.qiddm_qconv_train_backward(n_qubits, xx.data_ptr(), b, c, h, w, kh, kw, ph, pw, gy.data_ptr(),
+                                                   c_out, rt.data_ptr(), co, gfeat_t.data_ptr(), hpart.data_ptr(),
+                                                   0 if gx is None else gx.data_ptr(), _stream_ptr(device)))
+        # h_c (complex, D entries; every pad column shares one value) -> one adjoint sweep per output channel
+        hs = hpart.sum(dim=0, dtype=torch.float64)
+        hc = torch.complex(hs[:c_out], -hs[co:co + c_out])
+        psi0 = torch.empty(c_out, d, dtype=torch.complex128, device=device)
+        psi0[:, :f] = hc[:, :f]
+        psi0[:, f:] = hc[:, f:f + 1]
+        lam = torch.zeros(c_out, d, dtype=torch.complex128, device=device)
+        lam.view(c_out, d // 2, 2)[:, :c_out, 0] = torch.eye(c_out, dtype=torch.complex128, device=device)   # e_2c
+        ang = _as_f64(angles.detach(), device).contiguous()
+        circ = Circuit(n_qubits=n_qubits, encoding="none", imprimitive="CNOT", measure="probs", n_rounds=1,
+                       n_blocks=1, sel_layers=ang.shape[0])
+        cs = circ.c_struct("f64")
+        table = prepare_gates(circ, ang.reshape(circ.angles_shape), "f64")
+        n_rot = lib.qiddm_num_rot_gates(ctypes.byref(cs))
+        kparts = lib.qiddm_matrix_adjoint_partials(c_out)
+        kp = torch.empty(kparts, n_rot, 8, dtype=torch.float64, device=device)
+        need = lib.qiddm_matrix_adjoint_workspace_bytes(ctypes.byref(cs), c_out)
+        key = ("matrix-adjoint", device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+        ws = _workspaces.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _workspaces[key] = torch.empty(need, dtype=torch.uint8, device=device)
+        _capi.check(lib.qiddm_matrix_adjoint(ctypes.byref(cs), torch.view_as_real(psi0).data_ptr(),
+                                             torch.view_as_real(lam).data_ptr(), c_out, table.data_ptr(), kp.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), _stream_ptr(device)))
+        ga = torch.empty(n_rot, 3, dtype=torch.float64, device=device)
+        _capi.check(lib.qiddm_adjoint_finalize(ctypes.byref(cs), ang.data_ptr(), kp.data_ptr(), kparts,
+                                               ga.data_ptr(), _stream_ptr(device)))
+        return (None if gx is None else gx.to(x.dtype)), ga.reshape(angles.shape).to(angles.dtype), None, None, None, None
+
+
+def qconv_unitary_execute(x: torch.Tensor, angles: torch.Tensor, n_qubits: int, out_channels: int, kernel_size,
+                          padding) -> torch.Tensor:
+    """Differentiable QConv2d through the circuit unitary (float32 products; see ``qconv_unitary_trainable``)."""
+    return _QConvUnitaryFunction.apply(x, angles, n_qubits, out_channels, tuple(kernel_size), tuple(padding))
+
+
 def _norm_workspace(batch, channels, hw, device):
     need = _capi.lib().qiddm_batchnorm_workspace_bytes(batch, channels, hw)
     if need < 0:

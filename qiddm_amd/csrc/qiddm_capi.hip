@@ -510,7 +510,7 @@ int64_t wide_adjoint_blocks(int64_t batch) { return batch < 1 ? 1 : (batch < 512
 template <typename T>
 int launch_wide_adjoint(const qiddm_circuit_t* c, const void* inputs, const void* table, const void* gout,
                                void* k_partials, void* grad_inputs, void* ws, const qiddm::KScalars& p,
-                               int64_t gin_ld, hipStream_t st) {
+                               int64_t gin_ld, hipStream_t st, bool raw = false) {
   const int64_t n_rot = (int64_t)c->n_blocks * c->sel_layers * c->n_qubits;
   const size_t smem = ((size_t)n_rot * 8 + 64 + 48) * sizeof(T);
   if (smem > kMaxLds)
@@ -527,7 +527,9 @@ int launch_wide_adjoint(const qiddm_circuit_t* c, const void* inputs, const void
   qiddm::WideAdjointScalars ad;
   ad.gin_ld = gin_ld;
   ad.n = c->n_qubits;
-  ad.want_inputs = (grad_inputs != nullptr && c->encoding != QIDDM_ENC_NONE) ? 1 : 0;
+  ad.want_inputs = (!raw && grad_inputs != nullptr && c->encoding != QIDDM_ENC_NONE) ? 1 : 0;
+  ad.raw = raw ? 1 : 0;
+  ad.pad_ = 0;
   hipLaunchKernelGGL(kern, dim3((unsigned)wide_adjoint_blocks(p.batch)), dim3(qiddm::kWideThreads), smem, st,
                      static_cast<const T*>(inputs), static_cast<const T*>(table), static_cast<const T*>(gout),
                      static_cast<T*>(k_partials), static_cast<T*>(grad_inputs), static_cast<qiddm::V2<T>*>(ws), p, ad);
@@ -735,6 +737,37 @@ int qiddm_backward_adjoint_wide(const qiddm_circuit_t* c, const void* inputs, in
   return c->dtype == QIDDM_F32
              ? launch_wide_adjoint<float>(c, inputs, gate_table, grad_out, k_partials, grad_inputs, workspace, p, gin_ld, st)
              : launch_wide_adjoint<double>(c, inputs, gate_table, grad_out, k_partials, grad_inputs, workspace, p, gin_ld, st);
+}
+
+int64_t qiddm_matrix_adjoint_partials(int64_t count) { return count < 0 ? -1 : wide_adjoint_blocks(count); }
+
+int64_t qiddm_matrix_adjoint_workspace_bytes(const qiddm_circuit_t* c, int64_t count) {
+  if (check_circuit(c) != QIDDM_OK || count < 0) return -1;
+  return wide_adjoint_blocks(count) * 2 * ((int64_t)1 << c->n_qubits) * 16;
+}
+
+int qiddm_matrix_adjoint(const qiddm_circuit_t* c, const double* psi0, const double* lambda, int64_t count,
+                         const void* gate_table, void* k_partials, void* workspace, int64_t workspace_bytes,
+                         void* stream) {
+  int rc = check_circuit(c);
+  if (rc != QIDDM_OK) return rc;
+  if (c->n_rounds != 1) return fail(QIDDM_ERR_UNSUPPORTED, "one round only (n_rounds=%d)", c->n_rounds);
+  if (c->dtype != QIDDM_F64) return fail(QIDDM_ERR_UNSUPPORTED, "the matrix-element sweep runs in float64");
+  if (c->n_qubits < 2) return fail(QIDDM_ERR_UNSUPPORTED, "the matrix-element sweep needs n_qubits >= 2");
+  if (count < 0) return fail(QIDDM_ERR_INVALID, "count < 0");
+  if (!gate_table || !k_partials) return fail(QIDDM_ERR_INVALID, "gate_table/k_partials is NULL");
+  if (count > 0 && (!psi0 || !lambda)) return fail(QIDDM_ERR_INVALID, "psi0/lambda is NULL");
+  const int64_t need = qiddm_matrix_adjoint_workspace_bytes(c, count);
+  if (!workspace || workspace_bytes < need)
+    return fail(QIDDM_ERR_INVALID, "workspace of %lld B needed (qiddm_matrix_adjoint_workspace_bytes), got %lld",
+                (long long)need, (long long)workspace_bytes);
+  qiddm::KScalars p = make_params(c);
+  p.in_ld = (int64_t)2 << c->n_qubits;
+  p.g_ld = p.in_ld;
+  p.batch = count;
+  p.encoding = QIDDM_ENC_NONE;  // weight-only layers; the start vector is given
+  return launch_wide_adjoint<double>(c, psi0, gate_table, lambda, k_partials, nullptr, workspace, p, 0,
+                                     static_cast<hipStream_t>(stream), true);
 }
 
 int qiddm_backward_adjoint(const qiddm_circuit_t* c, const void* inputs, int64_t batch, int64_t in_ld,

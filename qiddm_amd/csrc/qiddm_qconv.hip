@@ -5,7 +5,9 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <cstring>
 
+#include "qsim_qconv_train.h"
 #include "qsim_unitary.h"
 
 namespace {
@@ -222,6 +224,84 @@ int qiddm_qconv_unitary_forward(int32_t n_qubits, const double* u, const double*
                        dim3(4 * qiddm::kWave), 0, st, x, w, padv, bnv, y, gc);
   e = hipGetLastError();
   if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_gemm_kernel launch failed: %s", hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
+int64_t qiddm_qconv_train_partials(int64_t batch, int64_t height_out, int64_t width_out) {
+  if (batch < 0 || height_out < 1 || width_out < 1) return -1;
+  const int64_t tiles = (batch * height_out * width_out + qiddm::kTcThreads - 1) / qiddm::kTcThreads;
+  return tiles < 1 ? 1 : (tiles < 512 ? tiles : 512);
+}
+
+int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch, int64_t in_channels, int64_t height,
+                               int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
+                               const double* grad_y, int64_t out_channels, const float* rows, int32_t row_channels,
+                               float* grad_features_t, float* h_partials, double* grad_x, void* stream) {
+  if (n_qubits < 1 || n_qubits > 12) return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d outside 1..12", n_qubits);
+  if (batch < 1 || in_channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad_h < 0 || pad_w < 0 ||
+      out_channels < 1)
+    return fail(QIDDM_ERR_INVALID, "bad convolution geometry");
+  if (kh > 15 || kw > 15 || in_channels * height * width >= (1 << 24))
+    return fail(QIDDM_ERR_UNSUPPORTED, "kernel larger than 15 or image plane stack beyond 2^24 elements");
+  const int64_t d = (int64_t)1 << n_qubits, f = in_channels * kh * kw;
+  if (f > d) return fail(QIDDM_ERR_INVALID, "in_channels*kh*kw=%lld exceeds 2^n=%lld", (long long)f, (long long)d);
+  if (2 * out_channels > d) return fail(QIDDM_ERR_INVALID, "out_channels beyond the even-index probabilities");
+  if (out_channels > row_channels) return fail(QIDDM_ERR_INVALID, "out_channels > row_channels");
+  const int64_t ho = height + 2 * pad_h - kh + 1, wo = width + 2 * pad_w - kw + 1;
+  if (ho < 1 || wo < 1) return fail(QIDDM_ERR_INVALID, "kernel larger than the padded image");
+  if (batch * ho * wo >= ((int64_t)1 << 40)) return fail(QIDDM_ERR_INVALID, "too many output pixels");
+  if (!x || !grad_y || !rows || !grad_features_t || !h_partials)
+    return fail(QIDDM_ERR_INVALID, "x/grad_y/rows/grad_features_t/h_partials is NULL");
+  const int jch = (int)((f + 1 + qiddm::kTcThreads - 1) / qiddm::kTcThreads);
+  qiddm::TrainConv tc;
+  std::memset(&tc, 0, sizeof(tc));
+  tc.C = (int32_t)in_channels;
+  tc.H = (int32_t)height;
+  tc.W = (int32_t)width;
+  tc.kh = (int32_t)kh;
+  tc.kw = (int32_t)kw;
+  tc.ph = (int32_t)pad_h;
+  tc.pw = (int32_t)pad_w;
+  tc.Ho = (int32_t)ho;
+  tc.Wo = (int32_t)wo;
+  tc.C_out = (int32_t)out_channels;
+  tc.F = (int32_t)f;
+  tc.M = batch * ho * wo;
+  tc.pad_norm2 = 0.25f * (float)(d - f);
+  tc.post_scale = 0.5f * (float)d;
+  const unsigned grid = (unsigned)qiddm_qconv_train_partials(batch, ho, wo);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  size_t smem = 0;
+  const void* kern = nullptr;
+#define QIDDM_TC_CASE(CO, J)                                                                      \
+  if (row_channels == CO && jch == J) {                                                           \
+    smem = qiddm::tc_lds_bytes<CO>((int)f);                                                       \
+    kern = reinterpret_cast<const void*>(qiddm::qconv_train_backward_kernel<CO, J>);              \
+  }
+  QIDDM_TC_CASE(8, 1)
+  QIDDM_TC_CASE(8, 2)
+  QIDDM_TC_CASE(16, 1)
+  QIDDM_TC_CASE(16, 2)
+  QIDDM_TC_CASE(32, 1)
+#undef QIDDM_TC_CASE
+  if (!kern)
+    return fail(QIDDM_ERR_UNSUPPORTED, "unitary-route backward: row_channels=%d with %lld features is outside "
+                "{8,16} x 511 / 32 x 255", row_channels, (long long)f);
+  if (smem > kMaxLds) return fail(QIDDM_ERR_UNSUPPORTED, "unitary-route backward needs %zu B of LDS", smem);
+  if (smem > 48 * 1024) {
+    const hipError_t ea = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    if (ea != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
+  }
+  void* args[] = {(void*)&x, (void*)&grad_y, (void*)&rows, (void*)&grad_features_t, (void*)&h_partials, (void*)&tc};
+  hipError_t e = hipLaunchKernel(kern, dim3(grid), dim3(qiddm::kTcThreads), args, smem, st);
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_train_backward_kernel launch failed: %s", hipGetErrorString(e));
+  if (grad_x) {
+    const int64_t total = batch * in_channels * height * width;
+    hipLaunchKernelGGL(qiddm::qconv_fold_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
+                       static_cast<const float*>(grad_features_t), grad_x, total, tc);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_fold_t_kernel launch failed: %s", hipGetErrorString(e));
+  }
   return QIDDM_OK;
 }
 

@@ -17,6 +17,10 @@ namespace qiddm {
 struct WideAdjointScalars {
   int64_t gin_ld;
   int32_t n, want_inputs;
+  // raw != 0: "matrix element" mode -- `inputs` rows are complex start vectors psi_0 (2 D reals, not normalised) and
+  // `gout` rows complex lambda at the circuit's end; the K slabs then give 2 Re <lambda| dU/dangle |psi_0> (the
+  // weight gradient of the quantum convolution from its per-channel h vectors, qsim_qconv_train.h)
+  int32_t raw, pad_;
 };
 
 constexpr int kWideThreads = 256;
@@ -163,7 +167,9 @@ __global__ __launch_bounds__(kWideThreads) void wide_adjoint_kernel(const T* __r
     }
     // ---- forward --------------------------------------------------------------------------------------------
     T amp_inv = 1;
-    if (p.encoding == 1) {
+    if (ad.raw) {
+      for (uint32_t k = tid; k < D; k += kWideThreads) psi[k] = C{in_row[2 * k], in_row[2 * k + 1]};
+    } else if (p.encoding == 1) {
       T part[1] = {0};
       for (uint32_t k = tid; k < D; k += kWideThreads) {
         const T v = k < (uint32_t)p.n_features ? in_row[k] + (T)p.enc_offset : (T)p.pad_with;
@@ -205,6 +211,10 @@ __global__ __launch_bounds__(kWideThreads) void wide_adjoint_kernel(const T* __r
     {
       const T* __restrict__ g_row = gout + sample * p.g_ld;
       for (uint32_t k = tid; k < D; k += kWideThreads) {
+        if (ad.raw) {
+          lam[k] = C{g_row[2 * k], g_row[2 * k + 1]};
+          continue;
+        }
         T g;
         if (p.measure == 0) {
           g = g_row[k];

@@ -1,0 +1,190 @@
+// qsim_qconv_train.h -- backward of the quantum convolution through the circuit's unitary.
+//
+// QConv2d's circuit does not depend on the data (reference nn/qconv.py:51-56: AmplitudeEmbedding, then
+// StronglyEntanglingLayers(weights)), so with U = U(weights) and the embedded patch v^ = v / |v| (real) every output
+// pixel m is  a_mc = sum_j U[2c, j] v^_mj,  y_mc = clamp(|a_mc|^2 D/2)  -- the GEMM the eval-mode route already runs.
+// Its derivative needs no per-pixel circuit sweep either.  With t_mc = dL/dy_mc * D/2 where the clamp passes:
+//
+//   dL/dv^_mj = 2 Re sum_c t_mc conj(a_mc) U[2c, j]                 (a second product with the same rows of U)
+//   dL/dv_mj  = (dL/dv^_mj - v^_mj * 2 sum_c t_mc |a_mc|^2) / |v_m|   (through the normalisation)
+//   dL/dtheta = 2 Re sum_c  e_2c^T (dU/dtheta) h_c,    h_c[j] = sum_m t_mc conj(a_mc) v^_mj
+//
+// i.e. the weight gradient is the adjoint sweep of C_out vectors h_c (a third product, reduced over the pixels)
+// instead of one sweep per output pixel.  This kernel computes all three products per tile of 256 pixels on the
+// VALU (2 C_out <= 64 rows: the operand is thin); the h_c sweep is `wide_adjoint_kernel` in its raw mode.
+//
+// Tables: rt[(F + 1)][2 CO] float32 -- rt[j][c] = Re U[2c, j], rt[j][CO + c] = Im U[2c, j], row F = the pad
+// columns' contribution 0.5 * sum_{j >= F} U[2c, j]; channels c >= C_out are zero.
+// Outputs: gfeat_t[F][M] (feature gradients, TRANSPOSED so that both this kernel's stores and the fold's loads are
+// coalesced) and hpart[grid][2 CO][F + 1] per-workgroup sums of W2_cc v^_j with W2 = (t Re a, t Im a)
+// (h_c = hsum[c] - i hsum[CO + c]; column F = the value every pad column shares).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace qiddm {
+
+struct TrainConv {
+  int32_t C, H, W, kh, kw, ph, pw, Ho, Wo, C_out, F, pad_;
+  int64_t M;          // batch * Ho * Wo
+  float pad_norm2;    // 0.25 * (D - F)
+  float post_scale;   // D / 2
+};
+
+constexpr int kTcThreads = 256;
+constexpr int kTcSub = 64;  // pixels staged per round of the h product
+
+__host__ __device__ inline int tc_v_stride(int F) { return (F + 1) | 1; }  // odd: conflict-free row writes
+template <int CO>
+__host__ __device__ inline size_t tc_lds_bytes(int F) {
+  return ((size_t)(F + 1) * 2 * CO + (size_t)kTcSub * tc_v_stride(F) + (size_t)kTcSub * (2 * CO + 1)) * sizeof(float) +
+         (size_t)F * sizeof(uint32_t);
+}
+
+template <int CO, int JCH>
+__global__ __launch_bounds__(kTcThreads) void qconv_train_backward_kernel(const double* __restrict__ x,
+                                                                          const double* __restrict__ gy,
+                                                                          const float* __restrict__ rt,
+                                                                          float* __restrict__ gfeat_t,
+                                                                          float* __restrict__ hpart,
+                                                                          const TrainConv tc) {
+  constexpr int K2 = 2 * CO, WS = K2 + 1;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int F = tc.F, FS = tc_v_stride(F);
+  float* s_rt = reinterpret_cast<float*>(smem_raw);  // [(F + 1)][K2]
+  float* s_v = s_rt + (size_t)(F + 1) * K2;          // [kTcSub][FS]
+  float* s_w = s_v + (size_t)kTcSub * FS;            // [kTcSub][WS]
+  uint32_t* s_tap = reinterpret_cast<uint32_t*>(s_w + (size_t)kTcSub * WS);  // [F]: offset | di << 24 | dj << 28
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < (F + 1) * K2; i += kTcThreads) s_rt[i] = rt[i];
+  for (int f = tid; f < F; f += kTcThreads) {
+    const int dj = f % tc.kw, t = f / tc.kw;
+    const int di = t % tc.kh, c = t / tc.kh;
+    s_tap[f] = (uint32_t)((c * tc.H + di) * tc.W + dj) | ((uint32_t)di << 24) | ((uint32_t)dj << 28);
+  }
+  __syncthreads();
+  float acc[JCH][K2];
+#pragma unroll
+  for (int jc = 0; jc < JCH; ++jc)
+#pragma unroll
+    for (int cc = 0; cc < K2; ++cc) acc[jc][cc] = 0.f;
+
+  const int64_t pixels = (int64_t)tc.Ho * tc.Wo;
+  const int64_t tiles = (tc.M + kTcThreads - 1) / kTcThreads;
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t m_raw = tile * kTcThreads + tid;
+    const bool valid = m_raw < tc.M;
+    const int64_t m = valid ? m_raw : tc.M - 1;
+    const int64_t b = m / pixels;
+    const int pix = (int)(m - b * pixels);
+    const int oi = pix / tc.Wo, oj = pix - oi * tc.Wo;
+    const int i0 = oi - tc.ph, j0 = oj - tc.pw;
+    const double* __restrict__ img = x + (size_t)b * tc.C * tc.H * tc.W + (ptrdiff_t)i0 * tc.W + j0;
+    auto feature = [&](int j) -> float {  // v_j = patch value + 0.1 (zero padding outside the image)
+      const uint32_t tap = s_tap[j];
+      const int ii = i0 + (int)((tap >> 24) & 15u), jj = j0 + (int)(tap >> 28);
+      float v = 0.f;
+      if (ii >= 0 && ii < tc.H && jj >= 0 && jj < tc.W) v = (float)img[tap & 0xffffffu];
+      return v + 0.1f;
+    };
+    // ---- a = U_rows v^ ---------------------------------------------------------------------------------------
+    float a[K2];
+#pragma unroll
+    for (int cc = 0; cc < K2; ++cc) a[cc] = 0.f;
+    float nrm2 = tc.pad_norm2;
+    for (int j = 0; j < F; ++j) {
+      const float v = feature(j);
+      nrm2 = fmaf(v, v, nrm2);
+      const float* __restrict__ r = s_rt + (size_t)j * K2;
+#pragma unroll
+      for (int cc = 0; cc < K2; ++cc) a[cc] = fmaf(r[cc], v, a[cc]);
+    }
+    const float inv = 1.0f / sqrtf(nrm2);
+    {
+      const float* __restrict__ r = s_rt + (size_t)F * K2;
+#pragma unroll
+      for (int cc = 0; cc < K2; ++cc) a[cc] = (a[cc] + r[cc]) * inv;
+    }
+    // ---- W2 = t (Re a, Im a), dot = 2 sum t |a|^2 ---------------------------------------------------------------
+    float dot = 0.f;
+    const double* __restrict__ gpix = gy + (size_t)b * tc.C_out * pixels + pix;
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+      const float p2 = a[c] * a[c] + a[CO + c] * a[CO + c];
+      float t = 0.f;
+      if (valid && c < tc.C_out && p2 * tc.post_scale <= 1.0f) t = (float)gpix[(size_t)c * pixels] * tc.post_scale;
+      dot = fmaf(2.0f * t, p2, dot);
+      a[c] *= t;
+      a[CO + c] *= t;
+    }
+    // ---- feature gradients ---------------------------------------------------------------------------------------
+    for (int j = 0; j < F; ++j) {
+      const float vh = feature(j) * inv;
+      const float* __restrict__ r = s_rt + (size_t)j * K2;
+      float s = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < K2; ++cc) s = fmaf(a[cc], r[cc], s);
+      if (valid) gfeat_t[(size_t)j * tc.M + m] = (2.0f * s - vh * dot) * inv;
+    }
+    // ---- h += W2^T v^ over the tile, 64 pixels at a time ------------------------------------------------------------
+    for (int sub = 0; sub < kTcThreads / kTcSub; ++sub) {
+      __syncthreads();
+      if (wave == sub) {
+#pragma unroll
+        for (int cc = 0; cc < K2; ++cc) s_w[lane * WS + cc] = a[cc];
+        for (int j = 0; j < F; ++j) s_v[lane * FS + j] = feature(j) * inv;
+        s_v[lane * FS + F] = 0.5f * inv;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int jc = 0; jc < JCH; ++jc) {
+        const int j = tid + jc * kTcThreads;
+        if (j <= F) {
+          for (int p = 0; p < kTcSub; ++p) {
+            const float v = s_v[p * FS + j];
+            const float* __restrict__ w = s_w + p * WS;
+#pragma unroll
+            for (int cc = 0; cc < K2; ++cc) acc[jc][cc] = fmaf(w[cc], v, acc[jc][cc]);
+          }
+        }
+      }
+    }
+  }
+  float* __restrict__ hp = hpart + (size_t)blockIdx.x * K2 * (F + 1);
+#pragma unroll
+  for (int jc = 0; jc < JCH; ++jc) {
+    const int j = tid + jc * kTcThreads;
+    if (j <= F) {
+#pragma unroll
+      for (int cc = 0; cc < K2; ++cc) hp[(size_t)cc * (F + 1) + j] = acc[jc][cc];
+    }
+  }
+}
+
+// dL/dx from the transposed feature gradients: every input element gathers the kh*kw patch entries it appeared in
+// (fixed order; neighbouring threads read neighbouring pixels of the same feature row: coalesced)
+__global__ __launch_bounds__(256) void qconv_fold_t_kernel(const float* __restrict__ gfeat_t, double* __restrict__ gx,
+                                                           int64_t total, const TrainConv tc) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int j = (int)(idx % tc.W);
+  int64_t t = idx / tc.W;
+  const int i = (int)(t % tc.H);
+  t /= tc.H;
+  const int c = (int)(t % tc.C);
+  const int64_t b = t / tc.C;
+  double accv = 0;
+  for (int di = 0; di < tc.kh; ++di) {
+    const int oi = i - di + tc.ph;
+    if (oi < 0 || oi >= tc.Ho) continue;
+    for (int dj = 0; dj < tc.kw; ++dj) {
+      const int oj = j - dj + tc.pw;
+      if (oj < 0 || oj >= tc.Wo) continue;
+      accv += (double)gfeat_t[(size_t)((c * tc.kh + di) * tc.kw + dj) * tc.M + (b * tc.Ho + oi) * tc.Wo + oj];
+    }
+  }
+  gx[idx] = accv;
+}
+
+}  // namespace qiddm

@@ -77,6 +77,12 @@ class QConv2d(torch.nn.Module):
             # inference: unfold + embedding + circuit + post-processing in one launch
             return _c.qconv_forward(x, _qw_tanh(self.weights.detach().double()), self.wires,
                                     self.out_channels, self.kernel_size, self.padding)
+        if (self.qnode is self._own_qnode and x.is_cuda and _c._default_precision == "f32"
+                and _c.qconv_unitary_trainable(self.wires, self.in_channels, self.kernel_size, self.out_channels)):
+            # training through the circuit unitary: GEMM forward, thin-product backward, one adjoint sweep per
+            # output channel (the circuit does not depend on the data)
+            return _c.qconv_unitary_execute(x.double(), _qw_tanh(self.weights.double()), self.wires,
+                                            self.out_channels, self.kernel_size, self.padding)
         if (self.qnode is self._own_qnode and self.wires <= 10 and x.is_cuda
                 and 2 * self.out_channels <= 2 ** self.wires):
             # training: the same fused launch, differentiable (adjoint sweep per output pixel + fold)

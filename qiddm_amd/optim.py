@@ -73,6 +73,8 @@ class FusedAdam(torch.optim.Optimizer):
                                             float(group["eps"]), float(group["weight_decay"]),
                                             self._sync(device).data_ptr(), ctypes.c_void_p(stream)))
             self._keepalive = entries      # until the stream has consumed them
+            for p, *_ in entries:          # the launch wrote the parameters behind autograd's back
+                torch.autograd.graph.increment_version(p)
         return loss
 
     def reset_state(self):

@@ -156,4 +156,8 @@ class GraphedTrainStep:
         if self.g_opt is not None:
             parallel.all_reduce_gradients(self._params)
             self.g_opt.replay()
+        # a replay changes the parameters without any Python-side in-place op: tell torch's version counters, which
+        # key the layers' caches of derived data (sampler tables, eval-mode circuit unitaries)
+        for p in self._params:
+            torch.autograd.graph.increment_version(p)
         return self._result

@@ -93,7 +93,12 @@ def test_qconv_stack_trains_through_the_adjoint():
     (16, 8, 1, 0, (4, 6), 2, "f64", 1e-9),      # the 1x1 `up_conv`
     (3, 2, 3, 0, (6, 6), 1, "f64", 1e-9),       # no padding: H_out < H
     (16, 16, 3, 1, (8, 8), 3, "f32", 2e-4),     # 144 features on 8 wires, float32 engine
-    (32, 32, 3, 1, (5, 5), 2, "f32", 2e-4),     # 288 features on 9 wires
+    (32, 32, 3, 1, (5, 5), 2, "f32", 2e-4),     # 288 features on 9 wires (per-pixel sweep: 32 channels x 289 columns)
+    # float32 default: training through the circuit unitary (GEMM forward, thin-product backward, one sweep per channel)
+    (1, 8, 3, 1, (6, 5), 3, "f32", 2e-4),       # first UNet layer
+    (16, 8, 1, 0, (4, 6), 2, "f32", 2e-4),      # 1x1 up_conv, no pad columns to speak of (16 features on 4 wires)
+    (32, 16, 3, 1, (5, 5), 2, "f32", 2e-4),     # 288 features: two column chunks per thread
+    (3, 2, 3, 0, (9, 40), 1, "f32", 2e-4),      # several pixel tiles, ragged last tile, no padding
 ])
 def test_fused_qconv_backward_vs_oracle_autograd(c_in, c_out, k, pad, hw, qdepth, precision, tol):
     """qiddm_qconv_backward (adjoint sweep with the patch and dL/dy read in place, then the fold): d/dweights and
