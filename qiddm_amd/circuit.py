@@ -565,7 +565,7 @@ def qconv_unitary_trainable(n_qubits: int, in_channels: int, kernel_size, out_ch
     if max(kernel_size) > 15 or f + 1 > (512 if co <= 16 else 256):
         return False
     v_stride = (f + 1) | 1
-    lds = ((f + 1) * 2 * co + 64 * v_stride + 64 * (2 * co + 1)) * 4 + f * 4
+    lds = ((f + 1) * 2 * co + 64 * v_stride + 64 * (2 * co + 1) + 4 * 64 * (co + 1) + 8 * 64) * 4 + f * 4
     return lds <= 160 * 1024
 
 

@@ -229,8 +229,8 @@ int qiddm_qconv_unitary_forward(int32_t n_qubits, const double* u, const double*
 
 int64_t qiddm_qconv_train_partials(int64_t batch, int64_t height_out, int64_t width_out) {
   if (batch < 0 || height_out < 1 || width_out < 1) return -1;
-  const int64_t tiles = (batch * height_out * width_out + qiddm::kTcThreads - 1) / qiddm::kTcThreads;
-  return tiles < 1 ? 1 : (tiles < 512 ? tiles : 512);
+  const int64_t tiles = (batch * height_out * width_out + qiddm::kTcTile - 1) / qiddm::kTcTile;
+  return tiles < 1 ? 1 : (tiles < 1024 ? tiles : 1024);
 }
 
 int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch, int64_t in_channels, int64_t height,

@@ -10,7 +10,7 @@
 //   dL/dtheta = 2 Re sum_c  e_2c^T (dU/dtheta) h_c,    h_c[j] = sum_m t_mc conj(a_mc) v^_mj
 //
 // i.e. the weight gradient is the adjoint sweep of C_out vectors h_c (a third product, reduced over the pixels)
-// instead of one sweep per output pixel.  This kernel computes all three products per tile of 256 pixels on the
+// instead of one sweep per output pixel.  This kernel computes all three products per tile of 64 pixels on the
 // VALU (2 C_out <= 64 rows: the operand is thin); the h_c sweep is `wide_adjoint_kernel` in its raw mode.
 //
 // Tables: rt[(F + 1)][2 CO] float32 -- rt[j][c] = Re U[2c, j], rt[j][CO + c] = Im U[2c, j], row F = the pad
@@ -33,12 +33,14 @@ struct TrainConv {
 };
 
 constexpr int kTcThreads = 256;
-constexpr int kTcSub = 64;  // pixels staged per round of the h product
+constexpr int kTcTile = 64;  // output pixels per tile: lane = pixel, the four waves split the feature columns
 
 __host__ __device__ inline int tc_v_stride(int F) { return (F + 1) | 1; }  // odd: conflict-free row writes
 template <int CO>
 __host__ __device__ inline size_t tc_lds_bytes(int F) {
-  return ((size_t)(F + 1) * 2 * CO + (size_t)kTcSub * tc_v_stride(F) + (size_t)kTcSub * (2 * CO + 1)) * sizeof(float) +
+  // rows table, v^ tile, W2 tile, cross-wave partials [4][64][CO + 1], per-pixel scalars [2][4][64], tap table
+  return ((size_t)(F + 1) * 2 * CO + (size_t)kTcTile * tc_v_stride(F) + (size_t)kTcTile * (2 * CO + 1) +
+          (size_t)4 * kTcTile * (CO + 1) + (size_t)8 * kTcTile) * sizeof(float) +
          (size_t)F * sizeof(uint32_t);
 }
 
@@ -49,31 +51,35 @@ __global__ __launch_bounds__(kTcThreads) void qconv_train_backward_kernel(const 
                                                                           float* __restrict__ gfeat_t,
                                                                           float* __restrict__ hpart,
                                                                           const TrainConv tc) {
-  constexpr int K2 = 2 * CO, WS = K2 + 1;
+  constexpr int K2 = 2 * CO, WS = K2 + 1, PS = CO + 1, CQ = CO / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int F = tc.F, FS = tc_v_stride(F);
   float* s_rt = reinterpret_cast<float*>(smem_raw);  // [(F + 1)][K2]
-  float* s_v = s_rt + (size_t)(F + 1) * K2;          // [kTcSub][FS]
-  float* s_w = s_v + (size_t)kTcSub * FS;            // [kTcSub][WS]
-  uint32_t* s_tap = reinterpret_cast<uint32_t*>(s_w + (size_t)kTcSub * WS);  // [F]: offset | di << 24 | dj << 28
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float* s_v = s_rt + (size_t)(F + 1) * K2;          // [kTcTile][FS]
+  float* s_w = s_v + (size_t)kTcTile * FS;           // [kTcTile][WS]
+  float* s_part = s_w + (size_t)kTcTile * WS;        // [4][kTcTile][PS]
+  float* s_sc = s_part + (size_t)4 * kTcTile * PS;   // [2][4][kTcTile]: norm^2 partials, dot partials
+  uint32_t* s_tap = reinterpret_cast<uint32_t*>(s_sc + 8 * kTcTile);  // [F]: offset | di << 24 | dj << 28
+  const int tid = threadIdx.x, q = tid >> 6, lane = tid & 63;
   for (int i = tid; i < (F + 1) * K2; i += kTcThreads) s_rt[i] = rt[i];
   for (int f = tid; f < F; f += kTcThreads) {
     const int dj = f % tc.kw, t = f / tc.kw;
     const int di = t % tc.kh, c = t / tc.kh;
     s_tap[f] = (uint32_t)((c * tc.H + di) * tc.W + dj) | ((uint32_t)di << 24) | ((uint32_t)dj << 28);
   }
-  __syncthreads();
   float acc[JCH][K2];
 #pragma unroll
   for (int jc = 0; jc < JCH; ++jc)
 #pragma unroll
     for (int cc = 0; cc < K2; ++cc) acc[jc][cc] = 0.f;
+  // this wave's quarter of the feature columns
+  const int jq = (F + 3) / 4;
+  const int j_lo = q * jq, j_hi = (j_lo + jq < F) ? j_lo + jq : F;
 
   const int64_t pixels = (int64_t)tc.Ho * tc.Wo;
-  const int64_t tiles = (tc.M + kTcThreads - 1) / kTcThreads;
+  const int64_t tiles = (tc.M + kTcTile - 1) / kTcTile;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const int64_t m_raw = tile * kTcThreads + tid;
+    const int64_t m_raw = tile * kTcTile + lane;
     const bool valid = m_raw < tc.M;
     const int64_t m = valid ? m_raw : tc.M - 1;
     const int64_t b = m / pixels;
@@ -88,65 +94,85 @@ __global__ __launch_bounds__(kTcThreads) void qconv_train_backward_kernel(const 
       if (ii >= 0 && ii < tc.H && jj >= 0 && jj < tc.W) v = (float)img[tap & 0xffffffu];
       return v + 0.1f;
     };
-    // ---- a = U_rows v^ ---------------------------------------------------------------------------------------
-    float a[K2];
-#pragma unroll
-    for (int cc = 0; cc < K2; ++cc) a[cc] = 0.f;
-    float nrm2 = tc.pad_norm2;
-    for (int j = 0; j < F; ++j) {
-      const float v = feature(j);
-      nrm2 = fmaf(v, v, nrm2);
-      const float* __restrict__ r = s_rt + (size_t)j * K2;
-#pragma unroll
-      for (int cc = 0; cc < K2; ++cc) a[cc] = fmaf(r[cc], v, a[cc]);
-    }
-    const float inv = 1.0f / sqrtf(nrm2);
+    __syncthreads();  // the previous tile's readers of s_v / s_w / s_part are done (and the tables are filled)
+    // ---- partial a = U_rows v over this wave's columns; the features are parked (unnormalised) in s_v ---------------
     {
-      const float* __restrict__ r = s_rt + (size_t)F * K2;
+      float a[K2];
 #pragma unroll
-      for (int cc = 0; cc < K2; ++cc) a[cc] = (a[cc] + r[cc]) * inv;
-    }
-    // ---- W2 = t (Re a, Im a), dot = 2 sum t |a|^2 ---------------------------------------------------------------
-    float dot = 0.f;
-    const double* __restrict__ gpix = gy + (size_t)b * tc.C_out * pixels + pix;
+      for (int cc = 0; cc < K2; ++cc) a[cc] = 0.f;
+      float n2 = 0.f;
+      for (int j = j_lo; j < j_hi; ++j) {
+        const float v = feature(j);
+        s_v[lane * FS + j] = v;
+        n2 = fmaf(v, v, n2);
+        const float* __restrict__ r = s_rt + (size_t)j * K2;
 #pragma unroll
-    for (int c = 0; c < CO; ++c) {
-      const float p2 = a[c] * a[c] + a[CO + c] * a[CO + c];
-      float t = 0.f;
-      if (valid && c < tc.C_out && p2 * tc.post_scale <= 1.0f) t = (float)gpix[(size_t)c * pixels] * tc.post_scale;
-      dot = fmaf(2.0f * t, p2, dot);
-      a[c] *= t;
-      a[CO + c] *= t;
-    }
-    // ---- feature gradients ---------------------------------------------------------------------------------------
-    for (int j = 0; j < F; ++j) {
-      const float vh = feature(j) * inv;
-      const float* __restrict__ r = s_rt + (size_t)j * K2;
-      float s = 0.f;
-#pragma unroll
-      for (int cc = 0; cc < K2; ++cc) s = fmaf(a[cc], r[cc], s);
-      if (valid) gfeat_t[(size_t)j * tc.M + m] = (2.0f * s - vh * dot) * inv;
-    }
-    // ---- h += W2^T v^ over the tile, 64 pixels at a time ------------------------------------------------------------
-    for (int sub = 0; sub < kTcThreads / kTcSub; ++sub) {
-      __syncthreads();
-      if (wave == sub) {
-#pragma unroll
-        for (int cc = 0; cc < K2; ++cc) s_w[lane * WS + cc] = a[cc];
-        for (int j = 0; j < F; ++j) s_v[lane * FS + j] = feature(j) * inv;
-        s_v[lane * FS + F] = 0.5f * inv;
+        for (int cc = 0; cc < K2; ++cc) a[cc] = fmaf(r[cc], v, a[cc]);
       }
+      s_sc[q * kTcTile + lane] = n2;
+      // cross-wave sum in two rounds (real parts, then imaginary parts) through [4][64][CO + 1]
+      float mine[2 * CQ];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int c = 0; c < CO; ++c) s_part[((size_t)q * kTcTile + lane) * PS + c] = a[half * CO + c];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < CQ; ++i) {
+          float t = 0.f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) t += s_part[((size_t)w * kTcTile + lane) * PS + q * CQ + i];
+          mine[half * CQ + i] = t;
+        }
+        __syncthreads();
+      }
+      const float nrm2 = tc.pad_norm2 + s_sc[lane] + s_sc[kTcTile + lane] + s_sc[2 * kTcTile + lane] +
+                         s_sc[3 * kTcTile + lane];
+      const float inv = 1.0f / sqrtf(nrm2);
+      // ---- this thread's channels: a, t, W2 = t (Re a, Im a) -> s_w; its share of dot = 2 sum t |a|^2 ------------------
+      const double* __restrict__ gpix = gy + (size_t)b * tc.C_out * pixels + pix;
+      const float* __restrict__ rp = s_rt + (size_t)F * K2;
+      float dotp = 0.f;
+#pragma unroll
+      for (int i = 0; i < CQ; ++i) {
+        const int c = q * CQ + i;
+        const float ar = (mine[i] + rp[c]) * inv, ai = (mine[CQ + i] + rp[CO + c]) * inv;
+        const float p2 = ar * ar + ai * ai;
+        float t = 0.f;
+        if (valid && c < tc.C_out && p2 * tc.post_scale <= 1.0f) t = (float)gpix[(size_t)c * pixels] * tc.post_scale;
+        dotp = fmaf(2.0f * t, p2, dotp);
+        s_w[lane * WS + c] = t * ar;
+        s_w[lane * WS + CO + c] = t * ai;
+      }
+      s_sc[4 * kTcTile + q * kTcTile + lane] = dotp;
       __syncthreads();
+      // ---- feature gradients over this wave's columns; s_v becomes v^ ------------------------------------------------
+      const float dot = s_sc[4 * kTcTile + lane] + s_sc[5 * kTcTile + lane] + s_sc[6 * kTcTile + lane] +
+                        s_sc[7 * kTcTile + lane];
 #pragma unroll
-      for (int jc = 0; jc < JCH; ++jc) {
-        const int j = tid + jc * kTcThreads;
-        if (j <= F) {
-          for (int p = 0; p < kTcSub; ++p) {
-            const float v = s_v[p * FS + j];
-            const float* __restrict__ w = s_w + p * WS;
+      for (int cc = 0; cc < K2; ++cc) a[cc] = s_w[lane * WS + cc];
+      for (int j = j_lo; j < j_hi; ++j) {
+        const float vh = s_v[lane * FS + j] * inv;
+        s_v[lane * FS + j] = vh;
+        const float* __restrict__ r = s_rt + (size_t)j * K2;
+        float sacc = 0.f;
 #pragma unroll
-            for (int cc = 0; cc < K2; ++cc) acc[jc][cc] = fmaf(w[cc], v, acc[jc][cc]);
-          }
+        for (int cc = 0; cc < K2; ++cc) sacc = fmaf(a[cc], r[cc], sacc);
+        if (valid) gfeat_t[(size_t)j * tc.M + m] = (2.0f * sacc - vh * dot) * inv;
+      }
+      if (q == 3) s_v[lane * FS + F] = 0.5f * inv;  // the value every pad column holds
+    }
+    __syncthreads();
+    // ---- h += W2^T v^ over the tile: thread = feature column -------------------------------------------------------------
+#pragma unroll
+    for (int jc = 0; jc < JCH; ++jc) {
+      const int j = tid + jc * kTcThreads;
+      if (j <= F) {
+        for (int p = 0; p < kTcTile; ++p) {
+          const float v = s_v[p * FS + j];
+          const float* __restrict__ w = s_w + p * WS;
+#pragma unroll
+          for (int cc = 0; cc < K2; ++cc) acc[jc][cc] = fmaf(w[cc], v, acc[jc][cc]);
         }
       }
     }
