@@ -394,6 +394,13 @@ int qiddm_batchnorm_backward(const double *x, const double *grad_y, int64_t batc
  * qiddm_matrix_adjoint: K slabs (-> qiddm_adjoint_finalize) of 2 Re <lambda_s| dU/dangle |psi0_s> summed over
  * `count` (psi0, lambda) pairs of complex128 vectors (count, 2^n, interleaved); circ->dtype QIDDM_F64, gate table
  * of that dtype, 2 <= n_qubits <= 16.                                                                        */
+/* the two small steps either side: `rows` from the unitary (qiddm_circuit_unitary[_wide]; u_transposed as there),
+ * and h_partials -> the (out_channels, 2^n) complex128 start vectors psi0 = h_c and lambda = e_2c of
+ * qiddm_matrix_adjoint                                                                                        */
+int qiddm_qconv_train_rows(int32_t n_qubits, const double *u, int32_t u_transposed, int64_t features,
+                           int64_t out_channels, int32_t row_channels, float *rows, void *stream);
+int qiddm_qconv_train_vectors(int32_t n_qubits, const float *h_partials, int64_t n_partials, int64_t features,
+                              int64_t out_channels, int32_t row_channels, double *psi0, double *lambda, void *stream);
 int64_t qiddm_qconv_train_partials(int64_t batch, int64_t height_out, int64_t width_out);
 int qiddm_qconv_train_backward(int32_t n_qubits, const double *x, int64_t batch, int64_t in_channels,
                                int64_t height, int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,

@@ -578,13 +578,13 @@ class _QConvUnitaryFunction(torch.autograd.Function):
     def forward(ctx, x, angles, n_qubits, out_channels, kernel_size, padding):
         u = circuit_unitary(angles.detach(), n_qubits, "CNOT")
         y = qconv_unitary_forward(x, u, n_qubits, out_channels, kernel_size, padding)
-        ctx.save_for_backward(x, angles, u[0:2 * out_channels:2, :].contiguous())
+        ctx.save_for_backward(x, angles, u)
         ctx.cfg = (n_qubits, out_channels, kernel_size, padding)
         return y
 
     @staticmethod
     def backward(ctx, grad_y):
-        x, angles, rows = ctx.saved_tensors
+        x, angles, u = ctx.saved_tensors
         n_qubits, c_out, (kh, kw), (ph, pw) = ctx.cfg
         device = x.device
         b, c, h, w = x.shape
@@ -593,13 +593,13 @@ class _QConvUnitaryFunction(torch.autograd.Function):
         m = b * ho * wo
         co = _row_channels(c_out)
         lib = _capi.lib()
+        st = _stream_ptr(device)
         # rows of U the outputs read: (F + 1, 2 CO) float32, last row = what the 0.5-valued pad columns add up to
-        rt = torch.zeros(f + 1, 2 * co, dtype=torch.float32, device=device)
-        rt[:f, :c_out] = rows.real[:, :f].t()
-        rt[:f, co:co + c_out] = rows.imag[:, :f].t()
-        pad_sum = 0.5 * rows[:, f:].sum(dim=1)
-        rt[f, :c_out] = pad_sum.real
-        rt[f, co:co + c_out] = pad_sum.imag
+        transposed = (not u.is_contiguous()) and u.transpose(0, 1).is_contiguous()
+        ur = torch.view_as_real(u.transpose(0, 1) if transposed else u.contiguous())
+        rt = torch.empty(f + 1, 2 * co, dtype=torch.float32, device=device)
+        _capi.check(lib.qiddm_qconv_train_rows(n_qubits, ur.data_ptr(), int(transposed), f, c_out, co, rt.data_ptr(),
+                                               st))
         xx = _as_f64(x, device).contiguous()
         gy = _as_f64(grad_y, device).contiguous()
         n_part = lib.qiddm_qconv_train_partials(b, ho, wo)
@@ -608,15 +608,12 @@ class _QConvUnitaryFunction(torch.autograd.Function):
         gx = torch.empty(b, c, h, w, dtype=torch.float64, device=device) if ctx.needs_input_grad[0] else None
         _capi.check(lib.qiddm_qconv_train_backward(n_qubits, xx.data_ptr(), b, c, h, w, kh, kw, ph, pw, gy.data_ptr(),
                                                    c_out, rt.data_ptr(), co, gfeat_t.data_ptr(), hpart.data_ptr(),
-                                                   0 if gx is None else gx.data_ptr(), _stream_ptr(device)))
+                                                   0 if gx is None else gx.data_ptr(), st))
         # h_c (complex, D entries; every pad column shares one value) -> one adjoint sweep per output channel
-        hs = hpart.sum(dim=0, dtype=torch.float64)
-        hc = torch.complex(hs[:c_out], -hs[co:co + c_out])
-        psi0 = torch.empty(c_out, d, dtype=torch.complex128, device=device)
-        psi0[:, :f] = hc[:, :f]
-        psi0[:, f:] = hc[:, f:f + 1]
-        lam = torch.zeros(c_out, d, dtype=torch.complex128, device=device)
-        lam.view(c_out, d // 2, 2)[:, :c_out, 0] = torch.eye(c_out, dtype=torch.complex128, device=device)   # e_2c
+        psi0 = torch.empty(c_out, d, 2, dtype=torch.float64, device=device)
+        lam = torch.empty(c_out, d, 2, dtype=torch.float64, device=device)
+        _capi.check(lib.qiddm_qconv_train_vectors(n_qubits, hpart.data_ptr(), n_part, f, c_out, co, psi0.data_ptr(),
+                                                  lam.data_ptr(), st))
         ang = _as_f64(angles.detach(), device).contiguous()
         circ = Circuit(n_qubits=n_qubits, encoding="none", imprimitive="CNOT", measure="probs", n_rounds=1,
                        n_blocks=1, sel_layers=ang.shape[0])
@@ -630,9 +627,8 @@ class _QConvUnitaryFunction(torch.autograd.Function):
         ws = _workspaces.get(key)
         if ws is None or ws.numel() < need:
             ws = _workspaces[key] = torch.empty(need, dtype=torch.uint8, device=device)
-        _capi.check(lib.qiddm_matrix_adjoint(ctypes.byref(cs), torch.view_as_real(psi0).data_ptr(),
-                                             torch.view_as_real(lam).data_ptr(), c_out, table.data_ptr(), kp.data_ptr(),
-                                             ws.data_ptr(), ws.numel(), _stream_ptr(device)))
+        _capi.check(lib.qiddm_matrix_adjoint(ctypes.byref(cs), psi0.data_ptr(), lam.data_ptr(), c_out, table.data_ptr(),
+                                             kp.data_ptr(), ws.data_ptr(), ws.numel(), st))
         ga = torch.empty(n_rot, 3, dtype=torch.float64, device=device)
         _capi.check(lib.qiddm_adjoint_finalize(ctypes.byref(cs), ang.data_ptr(), kp.data_ptr(), kparts,
                                                ga.data_ptr(), _stream_ptr(device)))

@@ -230,7 +230,7 @@ int qiddm_qconv_unitary_forward(int32_t n_qubits, const double* u, const double*
 int64_t qiddm_qconv_train_partials(int64_t batch, int64_t height_out, int64_t width_out) {
   if (batch < 0 || height_out < 1 || width_out < 1) return -1;
   const int64_t tiles = (batch * height_out * width_out + qiddm::kTcTile - 1) / qiddm::kTcTile;
-  return tiles < 1 ? 1 : (tiles < 1024 ? tiles : 1024);
+  return tiles < 1 ? 1 : (tiles < 512 ? tiles : 512);
 }
 
 int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch, int64_t in_channels, int64_t height,
@@ -302,6 +302,39 @@ int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch,
     e = hipGetLastError();
     if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_fold_t_kernel launch failed: %s", hipGetErrorString(e));
   }
+  return QIDDM_OK;
+}
+
+int qiddm_qconv_train_rows(int32_t n_qubits, const double* u, int32_t u_transposed, int64_t features,
+                           int64_t out_channels, int32_t row_channels, float* rows, void* stream) {
+  if (n_qubits < 1 || n_qubits > 12) return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d outside 1..12", n_qubits);
+  const int64_t d = (int64_t)1 << n_qubits;
+  if (features < 1 || features > d || out_channels < 1 || 2 * out_channels > d || out_channels > row_channels)
+    return fail(QIDDM_ERR_INVALID, "features / out_channels do not fit 2^n or row_channels");
+  if (!u || !rows) return fail(QIDDM_ERR_INVALID, "u/rows is NULL");
+  const int64_t total = (features + 1) * row_channels;
+  hipLaunchKernelGGL(qiddm::qconv_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), u, (int)u_transposed, (int)d, (int)features, (int)out_channels,
+                     (int)row_channels, rows);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_rows_kernel launch failed: %s", hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
+int qiddm_qconv_train_vectors(int32_t n_qubits, const float* h_partials, int64_t n_partials, int64_t features,
+                              int64_t out_channels, int32_t row_channels, double* psi0, double* lambda, void* stream) {
+  if (n_qubits < 1 || n_qubits > 12) return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d outside 1..12", n_qubits);
+  const int64_t d = (int64_t)1 << n_qubits;
+  if (features < 1 || features > d || out_channels < 1 || 2 * out_channels > d || out_channels > row_channels)
+    return fail(QIDDM_ERR_INVALID, "features / out_channels do not fit 2^n or row_channels");
+  if (n_partials < 1 || n_partials > (1 << 20)) return fail(QIDDM_ERR_INVALID, "n_partials out of range");
+  if (!h_partials || !psi0 || !lambda) return fail(QIDDM_ERR_INVALID, "h_partials/psi0/lambda is NULL");
+  hipLaunchKernelGGL(qiddm::qconv_vectors_kernel, dim3((unsigned)((features + 1 + 31) / 32), (unsigned)out_channels),
+                     dim3(256), 0,
+                     static_cast<hipStream_t>(stream), h_partials, (int)n_partials, (int)d, (int)features,
+                     (int)out_channels, (int)row_channels, psi0, lambda);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_vectors_kernel launch failed: %s", hipGetErrorString(e));
   return QIDDM_OK;
 }
 

@@ -188,6 +188,73 @@ __global__ __launch_bounds__(kTcThreads) void qconv_train_backward_kernel(const 
   }
 }
 
+// rows table of the backward from the circuit unitary u (D x D complex128; u[k][j] = <k|U|j>, or its transpose):
+// rt[j][c] = Re U[2c, j], rt[j][CO + c] = Im U[2c, j] for j < F, row F = 0.5 * sum_{j >= F} U[2c, j]
+__global__ __launch_bounds__(256) void qconv_rows_kernel(const double* __restrict__ u, int transposed, int D, int F,
+                                                         int C_out, int CO, float* __restrict__ rt) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (j, c) with j <= F
+  if (idx >= (F + 1) * CO) return;
+  const int j = idx / CO, c = idx - j * CO;
+  double re = 0, im = 0;
+  if (c < C_out) {
+    auto elem = [&](int col, double& r, double& i) {
+      const size_t at = transposed ? ((size_t)col * D + 2 * c) : ((size_t)2 * c * D + col);
+      r = u[2 * at];
+      i = u[2 * at + 1];
+    };
+    if (j < F) {
+      elem(j, re, im);
+    } else {
+      for (int col = F; col < D; ++col) {
+        double r, i;
+        elem(col, r, i);
+        re += r;
+        im += i;
+      }
+      re *= 0.5;
+      im *= 0.5;
+    }
+  }
+  rt[(size_t)j * 2 * CO + c] = (float)re;
+  rt[(size_t)j * 2 * CO + CO + c] = (float)im;
+}
+
+// h_c from the per-workgroup partial sums, laid out as the start vectors of the matrix-element sweep, and the
+// matching lambda = e_2c:  psi0[c][j] = sum_p hp[p][c][min(j, F)] - i sum_p hp[p][CO + c][min(j, F)]
+__global__ __launch_bounds__(256) void qconv_vectors_kernel(const float* __restrict__ hpart, int n_partials, int D,
+                                                            int F, int C_out, int CO, double* __restrict__ psi0,
+                                                            double* __restrict__ lambda) {
+  // workgroup = 32 columns x 8 slices of the partial slabs; blockIdx.y = channel
+  __shared__ double s_re[8][33], s_im[8][33];
+  const int jl = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + jl, c = blockIdx.y;
+  const size_t slab = (size_t)2 * CO * (F + 1);
+  double re = 0, im = 0;
+  if (j <= F) {
+    for (int p = pg; p < n_partials; p += 8) {
+      re += (double)hpart[p * slab + (size_t)c * (F + 1) + j];
+      im -= (double)hpart[p * slab + (size_t)(CO + c) * (F + 1) + j];
+    }
+  }
+  s_re[pg][jl] = re;
+  s_im[pg][jl] = im;
+  __syncthreads();
+  if (pg != 0 || j > F) return;
+  for (int g = 1; g < 8; ++g) {
+    re += s_re[g][jl];
+    im += s_im[g][jl];
+  }
+  double* row = psi0 + (size_t)c * 2 * D;
+  double* lrow = lambda + (size_t)c * 2 * D;
+  const int j_end = j < F ? j + 1 : D;  // column F stands for every pad column
+  for (int col = j; col < j_end; ++col) {
+    row[2 * col] = re;
+    row[2 * col + 1] = im;
+    lrow[2 * col] = col == 2 * c ? 1.0 : 0.0;
+    lrow[2 * col + 1] = 0.0;
+  }
+}
+
 // dL/dx from the transposed feature gradients: every input element gathers the kh*kw patch entries it appeared in
 // (fixed order; neighbouring threads read neighbouring pixels of the same feature row: coalesced)
 __global__ __launch_bounds__(256) void qconv_fold_t_kernel(const float* __restrict__ gfeat_t, double* __restrict__ gx,
