@@ -268,6 +268,29 @@ def secondary_measurements(dev, batch):
                 out[f"train_images_per_s_{tag}_graphed"] = xt.shape[0] * tau / t
         except Exception as e:  # pragma: no cover
             out[f"train_error_{tag}"] = repr(e)
+    try:
+        # unet_simple training step (Diffusion loss, backward through the quantum convolutions, Adam) on a quarter of
+        # the batch x tau = 10 noise levels: eager, then recorded into HIP graphs
+        from qiddm_amd.optim import FusedAdam
+        from qiddm_amd.trainer import GraphedTrainStep
+        torch.manual_seed(42)
+        unet_t = nn.UNetUndirectedS(3, 8, 3).to(dev, dtype=torch.double).train()
+        diff = models.Diffusion(unet_t, noise.add_normal_noise_multiple, "data", (IMG, IMG),
+                                torch.nn.MSELoss()).to(dev, dtype=torch.double).train()
+        xt = x.reshape(batch, -1)[: max(batch // 4, 1)]
+        opt = FusedAdam(diff.parameters(), lr=1e-3)
+
+        def ustep():
+            opt.zero_grad()
+            diff(x=xt, T=10)
+            opt.step()
+        t = _time_fn(ustep, 5, warm=2)
+        out["train_images_per_s_UNetUndirectedS(3,8,3)"] = xt.shape[0] * 10 / t
+        gstep = GraphedTrainStep(diff, opt, xt, T=10, noise="device")
+        t = _time_fn(lambda: gstep(xt), 20, warm=2)
+        out["train_images_per_s_UNetUndirectedS(3,8,3)_graphed"] = xt.shape[0] * 10 / t
+    except Exception as e:  # pragma: no cover
+        out["unet_train_error"] = repr(e)
     return out
 
 
