@@ -6,6 +6,7 @@ from qiddm_amd import nn
 from qiddm_amd.models import Diffusion
 
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+with_table = "--no-table" not in sys.argv       # under rocprofv3, skip torch's own profiler
 tau = 10
 torch.manual_seed(42)
 net = nn.UNetUndirectedS(3, 8, 3).to("cuda").to(torch.double).train()
@@ -30,10 +31,11 @@ for _ in range(n):
 torch.cuda.synchronize()
 t = (time.perf_counter() - t0) / n
 print(f"UNetUndirectedS(3,8,3) training step, batch {batch} x tau {tau}: {t*1e3:.1f} ms ({batch*tau/t:.0f} images/s)")
-from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
-    step(); torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=70))
+if with_table:
+    from torch.profiler import profile, ProfilerActivity
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        step(); torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=70))
 
 # the same step recorded into HIP graphs (device noise stream, one-launch Adam)
 from qiddm_amd.optim import FusedAdam
