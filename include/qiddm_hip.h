@@ -401,6 +401,12 @@ int qiddm_qconv_train_rows(int32_t n_qubits, const double *u, int32_t u_transpos
                            int64_t out_channels, int32_t row_channels, float *rows, void *stream);
 int qiddm_qconv_train_vectors(int32_t n_qubits, const float *h_partials, int64_t n_partials, int64_t features,
                               int64_t out_channels, int32_t row_channels, double *psi0, double *lambda, void *stream);
+/* the fold on its own: grad_x (batch, C, H, W) float64 from transposed feature gradients (C kh kw, batch Ho Wo)
+ * float32 -- the transpose of torch.nn.Unfold as a deterministic gather (layers too wide for the thin-product
+ * kernel compute the feature gradients with library GEMMs, qiddm_amd/circuit.py)                              */
+int qiddm_qconv_fold_features(const float *grad_features_t, int64_t batch, int64_t in_channels, int64_t height,
+                              int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, double *grad_x,
+                              void *stream);
 int64_t qiddm_qconv_train_partials(int64_t batch, int64_t height_out, int64_t width_out);
 int qiddm_qconv_train_backward(int32_t n_qubits, const double *x, int64_t batch, int64_t in_channels,
                                int64_t height, int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,

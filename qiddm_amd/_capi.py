@@ -57,6 +57,7 @@ EXPORTS = (
     "qiddm_qconv_unitary_workspace_bytes",
     "qiddm_qconv_unitary_forward",
     "qiddm_conv1x1_forward",
+    "qiddm_qconv_fold_features",
     "qiddm_qconv_train_rows",
     "qiddm_qconv_train_vectors",
     "qiddm_qconv_train_partials",
@@ -149,6 +150,8 @@ def _declare(lib):
     lib.qiddm_qconv_backward.restype = ctypes.c_int
     lib.qiddm_qconv_backward.argtypes = [P, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, vp, i64, vp, vp, vp, vp]
     dbl = ctypes.c_double
+    lib.qiddm_qconv_fold_features.restype = ctypes.c_int
+    lib.qiddm_qconv_fold_features.argtypes = [vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, vp]
     lib.qiddm_qconv_train_rows.restype = ctypes.c_int
     lib.qiddm_qconv_train_rows.argtypes = [ctypes.c_int32, vp, ctypes.c_int32, i64, i64, ctypes.c_int32, vp, vp]
     lib.qiddm_qconv_train_vectors.restype = ctypes.c_int

@@ -556,17 +556,107 @@ def _row_channels(out_channels: int):
     return None
 
 
-def qconv_unitary_trainable(n_qubits: int, in_channels: int, kernel_size, out_channels: int) -> bool:
-    """Whether the unitary-route backward (``qiddm_qconv_train_backward``) covers this layer."""
-    co = _row_channels(out_channels)
+def qconv_unitary_route(n_qubits: int, in_channels: int, kernel_size, out_channels: int):
+    """Which backward serves a QConv2d trained through its circuit unitary: ``"thin"`` (the hand-written
+    thin-product kernel, ``qiddm_qconv_train_backward``: <= 32 output channels), ``"gemm"`` (wider layers, e.g. C4's
+    256 channels on 12 wires: the same three products as library GEMMs over batch chunks) or None."""
     f = in_channels * kernel_size[0] * kernel_size[1]
-    if co is None or not 2 <= n_qubits <= 12 or 2 * out_channels > 2 ** n_qubits or f > 2 ** n_qubits:
-        return False
-    if max(kernel_size) > 15 or f + 1 > (512 if co <= 16 else 256):
-        return False
-    v_stride = (f + 1) | 1
-    lds = ((f + 1) * 2 * co + 64 * v_stride + 64 * (2 * co + 1) + 4 * 64 * (co + 1) + 8 * 64) * 4 + f * 4
-    return lds <= 160 * 1024
+    if not 2 <= n_qubits <= 12 or 2 * out_channels > 2 ** n_qubits or f > 2 ** n_qubits:
+        return None
+    co = _row_channels(out_channels)
+    if co is not None and max(kernel_size) <= 15 and f + 1 <= (512 if co <= 16 else 256):
+        v_stride = (f + 1) | 1
+        lds = ((f + 1) * 2 * co + 64 * v_stride + 64 * (2 * co + 1) + 4 * 64 * (co + 1) + 8 * 64) * 4 + f * 4
+        if lds <= 160 * 1024:
+            return "thin"
+    return "gemm"
+
+
+def qconv_unitary_trainable(n_qubits: int, in_channels: int, kernel_size, out_channels: int) -> bool:
+    return qconv_unitary_route(n_qubits, in_channels, kernel_size, out_channels) is not None
+
+
+def _unitary_rows(u, n_qubits, f, c_out, co, device):
+    """(F + 1, 2 co) float32 rows table of the backward (``qiddm_qconv_train_rows``)."""
+    transposed = (not u.is_contiguous()) and u.transpose(0, 1).is_contiguous()
+    ur = torch.view_as_real(u.transpose(0, 1) if transposed else u.contiguous())
+    rt = torch.empty(f + 1, 2 * co, dtype=torch.float32, device=device)
+    _capi.check(_capi.lib().qiddm_qconv_train_rows(n_qubits, ur.data_ptr(), int(transposed), f, c_out, co,
+                                                   rt.data_ptr(), _stream_ptr(device)))
+    return rt
+
+
+def _angle_grads_from_h(hpart, n_part, angles, n_qubits, f, c_out, co, device):
+    """dL/dangles = 2 Re sum_c <e_2c| dU/dangle |h_c> from the h partial slabs: start vectors
+    (``qiddm_qconv_train_vectors``), one adjoint sweep per channel (``qiddm_matrix_adjoint``), finalize."""
+    lib = _capi.lib()
+    st = _stream_ptr(device)
+    d = 1 << n_qubits
+    psi0 = torch.empty(c_out, d, 2, dtype=torch.float64, device=device)
+    lam = torch.empty(c_out, d, 2, dtype=torch.float64, device=device)
+    _capi.check(lib.qiddm_qconv_train_vectors(n_qubits, hpart.data_ptr(), n_part, f, c_out, co, psi0.data_ptr(),
+                                              lam.data_ptr(), st))
+    ang = _as_f64(angles.detach(), device).contiguous()
+    circ = Circuit(n_qubits=n_qubits, encoding="none", imprimitive="CNOT", measure="probs", n_rounds=1,
+                   n_blocks=1, sel_layers=ang.shape[0])
+    cs = circ.c_struct("f64")
+    table = prepare_gates(circ, ang.reshape(circ.angles_shape), "f64")
+    n_rot = lib.qiddm_num_rot_gates(ctypes.byref(cs))
+    kparts = lib.qiddm_matrix_adjoint_partials(c_out)
+    kp = torch.empty(kparts, n_rot, 8, dtype=torch.float64, device=device)
+    need = lib.qiddm_matrix_adjoint_workspace_bytes(ctypes.byref(cs), c_out)
+    key = ("matrix-adjoint", device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _workspaces[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    _capi.check(lib.qiddm_matrix_adjoint(ctypes.byref(cs), psi0.data_ptr(), lam.data_ptr(), c_out, table.data_ptr(),
+                                         kp.data_ptr(), ws.data_ptr(), ws.numel(), st))
+    ga = torch.empty(n_rot, 3, dtype=torch.float64, device=device)
+    _capi.check(lib.qiddm_adjoint_finalize(ctypes.byref(cs), ang.data_ptr(), kp.data_ptr(), kparts, ga.data_ptr(), st))
+    return ga.reshape(angles.shape)
+
+
+_GEMM_CHUNK_BYTES = 256 << 20      # patch matrix of one batch chunk on the "gemm" route
+
+
+def _qconv_unitary_backward_gemm(x, grad_y, u, n_qubits, c_out, kernel_size, padding, need_gx):
+    """The three products of the unitary-route backward as float32 library GEMMs (rocBLAS through torch) over batch
+    chunks -- for layers beyond the thin-product kernel (C4: 2304 patch features x 512 columns).  Same formulas as
+    qsim_qconv_train.h; the fold, the start vectors and the per-channel sweeps are the same HIP entry points."""
+    from .nn.utils import unfold_patches
+    device = x.device
+    b, c, h, w = x.shape
+    kh, kw = kernel_size
+    ph, pw = padding
+    f, d = c * kh * kw, 1 << n_qubits
+    ho, wo = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+    rt = _unitary_rows(u, n_qubits, f, c_out, c_out, device)
+    r, rp = rt[:f], rt[f]                                   # (F, 2C), (2C)
+    post = 0.5 * d
+    hsum = torch.zeros(2 * c_out, f + 1, dtype=torch.float64, device=device)
+    gx = torch.empty(b, c, h, w, dtype=torch.float64, device=device) if need_gx else None
+    chunk = max(1, min(b, _GEMM_CHUNK_BYTES // max(ho * wo * f * 4, 1)))
+    lib = _capi.lib()
+    for b0 in range(0, b, chunk):
+        xb = x[b0:b0 + chunk]
+        cb = xb.shape[0]
+        v = unfold_patches(xb.to(torch.float32), kernel_size, padding) + 0.1          # (Mc, F)
+        inv = ((v * v).sum(dim=1, keepdim=True) + 0.25 * (d - f)).rsqrt()
+        a = torch.addmm(rp, v, r) * inv                                                # (Mc, 2C): Re | Im
+        p2 = a[:, :c_out] ** 2 + a[:, c_out:] ** 2
+        g = grad_y[b0:b0 + cb].permute(0, 2, 3, 1).reshape(-1, c_out).to(torch.float32)
+        t = torch.where(p2 * post <= 1.0, g * post, torch.zeros_like(g))
+        dot = 2.0 * (t * p2).sum(dim=1, keepdim=True)
+        w2 = torch.cat([t * a[:, :c_out], t * a[:, c_out:]], dim=1)                    # (Mc, 2C)
+        v *= inv                                                                       # v^
+        hsum[:, :f] += (w2.t() @ v).double()
+        hsum[:, f] += (w2.t() @ (0.5 * inv)).double()[:, 0]
+        if need_gx:
+            gft = (2.0 * (r @ w2.t()) - v.t() * dot.t()) * inv.t()                     # (F, Mc), transposed gradients
+            gft = gft.contiguous()
+            _capi.check(lib.qiddm_qconv_fold_features(gft.data_ptr(), cb, c, h, w, kh, kw, ph, pw,
+                                                      gx[b0:b0 + cb].data_ptr(), _stream_ptr(device)))
+    return hsum.to(torch.float32).unsqueeze(0).contiguous(), gx
 
 
 class _QConvUnitaryFunction(torch.autograd.Function):
@@ -588,51 +678,28 @@ class _QConvUnitaryFunction(torch.autograd.Function):
         n_qubits, c_out, (kh, kw), (ph, pw) = ctx.cfg
         device = x.device
         b, c, h, w = x.shape
-        f, d = c * kh * kw, 1 << n_qubits
+        f = c * kh * kw
         ho, wo = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
-        m = b * ho * wo
+        need_gx = ctx.needs_input_grad[0]
+        if qconv_unitary_route(n_qubits, c, (kh, kw), c_out) == "gemm":
+            hpart, gx = _qconv_unitary_backward_gemm(x, grad_y, u, n_qubits, c_out, (kh, kw), (ph, pw), need_gx)
+            ga = _angle_grads_from_h(hpart, 1, angles, n_qubits, f, c_out, c_out, device)
+            return (None if gx is None else gx.to(x.dtype)), ga.to(angles.dtype), None, None, None, None
         co = _row_channels(c_out)
         lib = _capi.lib()
         st = _stream_ptr(device)
-        # rows of U the outputs read: (F + 1, 2 CO) float32, last row = what the 0.5-valued pad columns add up to
-        transposed = (not u.is_contiguous()) and u.transpose(0, 1).is_contiguous()
-        ur = torch.view_as_real(u.transpose(0, 1) if transposed else u.contiguous())
-        rt = torch.empty(f + 1, 2 * co, dtype=torch.float32, device=device)
-        _capi.check(lib.qiddm_qconv_train_rows(n_qubits, ur.data_ptr(), int(transposed), f, c_out, co, rt.data_ptr(),
-                                               st))
+        rt = _unitary_rows(u, n_qubits, f, c_out, co, device)
         xx = _as_f64(x, device).contiguous()
         gy = _as_f64(grad_y, device).contiguous()
         n_part = lib.qiddm_qconv_train_partials(b, ho, wo)
-        gfeat_t = torch.empty(f, m, dtype=torch.float32, device=device)
+        gfeat_t = torch.empty(f, b * ho * wo, dtype=torch.float32, device=device)
         hpart = torch.empty(n_part, 2 * co, f + 1, dtype=torch.float32, device=device)
-        gx = torch.empty(b, c, h, w, dtype=torch.float64, device=device) if ctx.needs_input_grad[0] else None
+        gx = torch.empty(b, c, h, w, dtype=torch.float64, device=device) if need_gx else None
         _capi.check(lib.qiddm_qconv_train_backward(n_qubits, xx.data_ptr(), b, c, h, w, kh, kw, ph, pw, gy.data_ptr(),
                                                    c_out, rt.data_ptr(), co, gfeat_t.data_ptr(), hpart.data_ptr(),
                                                    0 if gx is None else gx.data_ptr(), st))
-        # h_c (complex, D entries; every pad column shares one value) -> one adjoint sweep per output channel
-        psi0 = torch.empty(c_out, d, 2, dtype=torch.float64, device=device)
-        lam = torch.empty(c_out, d, 2, dtype=torch.float64, device=device)
-        _capi.check(lib.qiddm_qconv_train_vectors(n_qubits, hpart.data_ptr(), n_part, f, c_out, co, psi0.data_ptr(),
-                                                  lam.data_ptr(), st))
-        ang = _as_f64(angles.detach(), device).contiguous()
-        circ = Circuit(n_qubits=n_qubits, encoding="none", imprimitive="CNOT", measure="probs", n_rounds=1,
-                       n_blocks=1, sel_layers=ang.shape[0])
-        cs = circ.c_struct("f64")
-        table = prepare_gates(circ, ang.reshape(circ.angles_shape), "f64")
-        n_rot = lib.qiddm_num_rot_gates(ctypes.byref(cs))
-        kparts = lib.qiddm_matrix_adjoint_partials(c_out)
-        kp = torch.empty(kparts, n_rot, 8, dtype=torch.float64, device=device)
-        need = lib.qiddm_matrix_adjoint_workspace_bytes(ctypes.byref(cs), c_out)
-        key = ("matrix-adjoint", device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
-        ws = _workspaces.get(key)
-        if ws is None or ws.numel() < need:
-            ws = _workspaces[key] = torch.empty(need, dtype=torch.uint8, device=device)
-        _capi.check(lib.qiddm_matrix_adjoint(ctypes.byref(cs), psi0.data_ptr(), lam.data_ptr(), c_out, table.data_ptr(),
-                                             kp.data_ptr(), ws.data_ptr(), ws.numel(), st))
-        ga = torch.empty(n_rot, 3, dtype=torch.float64, device=device)
-        _capi.check(lib.qiddm_adjoint_finalize(ctypes.byref(cs), ang.data_ptr(), kp.data_ptr(), kparts,
-                                               ga.data_ptr(), _stream_ptr(device)))
-        return (None if gx is None else gx.to(x.dtype)), ga.reshape(angles.shape).to(angles.dtype), None, None, None, None
+        ga = _angle_grads_from_h(hpart, n_part, angles, n_qubits, f, c_out, co, device)
+        return (None if gx is None else gx.to(x.dtype)), ga.to(angles.dtype), None, None, None, None
 
 
 def qconv_unitary_execute(x: torch.Tensor, angles: torch.Tensor, n_qubits: int, out_channels: int, kernel_size,

@@ -305,6 +305,36 @@ int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch,
   return QIDDM_OK;
 }
 
+int qiddm_qconv_fold_features(const float* grad_features_t, int64_t batch, int64_t in_channels, int64_t height,
+                              int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, double* grad_x,
+                              void* stream) {
+  if (batch < 1 || in_channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad_h < 0 || pad_w < 0)
+    return fail(QIDDM_ERR_INVALID, "bad convolution geometry");
+  const int64_t ho = height + 2 * pad_h - kh + 1, wo = width + 2 * pad_w - kw + 1;
+  if (ho < 1 || wo < 1) return fail(QIDDM_ERR_INVALID, "kernel larger than the padded image");
+  if (!grad_features_t || !grad_x) return fail(QIDDM_ERR_INVALID, "grad_features_t/grad_x is NULL");
+  const int64_t total = batch * in_channels * height * width;
+  if (total >= ((int64_t)1 << 40)) return fail(QIDDM_ERR_INVALID, "image batch too large");
+  qiddm::TrainConv tc;
+  std::memset(&tc, 0, sizeof(tc));
+  tc.C = (int32_t)in_channels;
+  tc.H = (int32_t)height;
+  tc.W = (int32_t)width;
+  tc.kh = (int32_t)kh;
+  tc.kw = (int32_t)kw;
+  tc.ph = (int32_t)pad_h;
+  tc.pw = (int32_t)pad_w;
+  tc.Ho = (int32_t)ho;
+  tc.Wo = (int32_t)wo;
+  tc.F = (int32_t)(in_channels * kh * kw);
+  tc.M = batch * ho * wo;
+  hipLaunchKernelGGL(qiddm::qconv_fold_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), grad_features_t, grad_x, total, tc);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_fold_t_kernel launch failed: %s", hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
 int qiddm_qconv_train_rows(int32_t n_qubits, const double* u, int32_t u_transposed, int64_t features,
                            int64_t out_channels, int32_t row_channels, float* rows, void* stream) {
   if (n_qubits < 1 || n_qubits > 12) return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d outside 1..12", n_qubits);

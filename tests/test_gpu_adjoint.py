@@ -211,3 +211,31 @@ def test_twelve_qubit_qconv_trains_through_the_wide_adjoint():
     assert (layer.weights.grad.cpu() - wo.grad).abs().max().item() < 1e-8 * sw
     sx = max(xo.grad.abs().max().item(), 1e-12)
     assert (xd.grad.cpu() - xo.grad).abs().max().item() < 1e-8 * sx
+
+
+@pytest.mark.parametrize("c_in,c_out,hw,batch", [(256, 48, (3, 3), 3), (64, 40, (4, 4), 2)])
+def test_wide_qconv_trains_through_the_unitary_gemm_route(c_in, c_out, hw, batch, monkeypatch):
+    """Layers beyond the thin-product kernel (C4's 12-wire shape: 2304 patch features; 40+ output channels): float32
+    training through the circuit unitary with the three backward products as library GEMMs over batch chunks, against
+    autograd through the oracle.  The chunk size is forced down so that several chunks (and a ragged last one) run."""
+    from oracle import circuits as oc
+    from qiddm_amd import circuit as qc
+    from qiddm_amd import nn
+    torch.manual_seed(9)
+    layer = nn.QConv2d(c_in, c_out, qdepth=2).to("cuda").train()
+    assert qc.qconv_unitary_route(layer.wires, c_in, (3, 3), c_out) == "gemm"
+    monkeypatch.setattr(qc, "_GEMM_CHUNK_BYTES", 2 * hw[0] * hw[1] * c_in * 9 * 4)      # two images per chunk
+    x = torch.rand(batch, c_in, *hw, dtype=torch.float64)
+    g = torch.randn(batch, c_out, *hw, dtype=torch.float64)
+    wo = layer.weights.detach().cpu().clone().requires_grad_(True)
+    xo = x.clone().requires_grad_(True)
+    yo = oc.qconv2d_forward(xo, wo, c_out, (3, 3), (1, 1))
+    (yo * g).sum().backward()
+    xd = x.to("cuda").requires_grad_(True)
+    yd = layer(xd)
+    (yd * g.to("cuda")).sum().backward()
+    assert (yd.cpu() - yo.detach()).abs().max().item() < 2e-4
+    sw = max(wo.grad.abs().max().item(), 1e-12)
+    assert (layer.weights.grad.cpu() - wo.grad).abs().max().item() < 2e-3 * sw
+    sx = max(xo.grad.abs().max().item(), 1e-12)
+    assert (xd.grad.cpu() - xo.grad).abs().max().item() < 2e-3 * sx
