@@ -200,6 +200,18 @@ def secondary_measurements(dev, batch):
     except Exception as e:  # pragma: no cover
         out["ll_error"] = repr(e)
     try:
+        # the reference's own MNIST default (src/mnist_exm.py:46): 6 qubits, 14 x 2 layers, two rounds (G = 840)
+        torch.manual_seed(42)
+        ll6 = nn.QIDDM_LL_noise(IMG * IMG, 6, 14, 2).to(dev, dtype=torch.double).eval()
+        ll6_diff = models.Diffusion(ll6, noise.add_normal_noise_multiple, "data", (IMG, IMG)).to(dev, dtype=torch.double).eval()
+        run, _ = make_runner(ll6_diff, x, True, 15)
+        run(150)
+        t = _time_fn(lambda: run(75), 20) / 75
+        out["denoise_images_per_s_QIDDM_LL_noise(784,6,14,2)"] = batch / t
+        out["gate_apps_per_s_QIDDM_LL_noise(784,6,14,2)"] = batch * 840 / t
+    except Exception as e:  # pragma: no cover
+        out["ll6_error"] = repr(e)
+    try:
         torch.manual_seed(42)
         unet = nn.UNetUndirectedS(3, 8, 3).to(dev, dtype=torch.double).eval()
         xb = x

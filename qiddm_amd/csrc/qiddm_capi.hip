@@ -264,6 +264,8 @@ int dispatch_qconv(int n, const double* x, const double* angles, double* y, cons
 template <typename T>
 size_t quad_lds_bytes(int n, int64_t n_rot) {
   switch (n) {
+    case 6: return qiddm::QuadSmem<T, 6>::bytes(n_rot);
+    case 7: return qiddm::QuadSmem<T, 7>::bytes(n_rot);
     case 8: return qiddm::QuadSmem<T, 8>::bytes(n_rot);
     case 9: return qiddm::QuadSmem<T, 9>::bytes(n_rot);
     default: return qiddm::QuadSmem<T, 10>::bytes(n_rot);
@@ -271,7 +273,7 @@ size_t quad_lds_bytes(int n, int64_t n_rot) {
 }
 
 bool quad_supported(const qiddm_circuit_t* c, int64_t in_features, int64_t out_features) {
-  if (!(c->n_qubits >= 8 && c->n_qubits <= 10 && c->imprimitive == QIDDM_IMP_CZ &&
+  if (!(c->n_qubits >= 6 && c->n_qubits <= 10 && c->imprimitive == QIDDM_IMP_CZ &&
         c->encoding == QIDDM_ENC_RZ && c->measure == QIDDM_MEAS_EXPZ && in_features <= 2048 && out_features <= 2048))
     return false;
   // its per-layer phase tables must fit in LDS (deep float64 circuits at n = 10 do not)
@@ -318,6 +320,8 @@ size_t quad_tables_bytes_n(int64_t n_rot) {
 template <typename T>
 size_t quad_tables_bytes(int n, int64_t n_rot) {
   switch (n) {
+    case 6: return quad_tables_bytes_n<T, 6>(n_rot);
+    case 7: return quad_tables_bytes_n<T, 7>(n_rot);
     case 8: return quad_tables_bytes_n<T, 8>(n_rot);
     case 9: return quad_tables_bytes_n<T, 9>(n_rot);
     default: return quad_tables_bytes_n<T, 10>(n_rot);
@@ -338,6 +342,8 @@ int dispatch_quad(int n, const double* x, const double* wd, const double* bd, co
                   const double* wu, const double* bu, double* y, const void* tables, const qiddm::QuadScalars& d,
                   const qiddm::KScalars& p, hipStream_t st) {
   switch (n) {
+    case 6: return launch_quad<T, 6>(x, wd, bd, angles, wu, bu, y, tables, d, p, st);
+    case 7: return launch_quad<T, 7>(x, wd, bd, angles, wu, bu, y, tables, d, p, st);
     case 8: return launch_quad<T, 8>(x, wd, bd, angles, wu, bu, y, tables, d, p, st);
     case 9: return launch_quad<T, 9>(x, wd, bd, angles, wu, bu, y, tables, d, p, st);
     case 10: return launch_quad<T, 10>(x, wd, bd, angles, wu, bu, y, tables, d, p, st);
@@ -1018,7 +1024,7 @@ int qiddm_dense_sample(const qiddm_circuit_t* c, const double* x, int64_t batch,
   if (batch < 0 || n_steps < 0) return fail(QIDDM_ERR_INVALID, "negative batch / n_steps");
   if (in_features < 1 || out_features < 1) return fail(QIDDM_ERR_INVALID, "bad feature counts");
   if (!quad_supported(c, in_features, out_features))
-    return fail(QIDDM_ERR_UNSUPPORTED, "fused sampling loop: needs 8 <= n <= 10, CZ, RZ encoding, <Z>, "
+    return fail(QIDDM_ERR_UNSUPPORTED, "fused sampling loop: needs 6 <= n <= 10, CZ, RZ encoding, <Z>, "
                 "features <= 2048");
   if (post_mode != 0 && post_mode != 1) return fail(QIDDM_ERR_INVALID, "post_mode must be 0 or 1");
   if ((post_mode == 1 || n_steps > 1) && in_features != out_features)
@@ -1067,6 +1073,8 @@ int qiddm_dense_sample_prepare(const qiddm_circuit_t* c, const double* angles, v
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool f32 = c->dtype == QIDDM_F32;
   switch (c->n_qubits) {
+    case 6: return f32 ? launch_quad_tables<float, 6>(angles, tables, p, n_rot, st) : launch_quad_tables<double, 6>(angles, tables, p, n_rot, st);
+    case 7: return f32 ? launch_quad_tables<float, 7>(angles, tables, p, n_rot, st) : launch_quad_tables<double, 7>(angles, tables, p, n_rot, st);
     case 8: return f32 ? launch_quad_tables<float, 8>(angles, tables, p, n_rot, st) : launch_quad_tables<double, 8>(angles, tables, p, n_rot, st);
     case 9: return f32 ? launch_quad_tables<float, 9>(angles, tables, p, n_rot, st) : launch_quad_tables<double, 9>(angles, tables, p, n_rot, st);
     default: return f32 ? launch_quad_tables<float, 10>(angles, tables, p, n_rot, st) : launch_quad_tables<double, 10>(angles, tables, p, n_rot, st);

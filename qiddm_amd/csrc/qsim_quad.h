@@ -10,7 +10,10 @@
 // threads, and the whole sampling loop x <- net(x) (reference src/models.py:124-136) can run for
 // `n_steps` iterations inside the launch with x held in registers.
 //
-// Restricted to what the dense nets need: RZ data re-uploading, CZ rings, <Z> read-out, 8 <= n <= 10.
+// Restricted to what the dense nets need: RZ data re-uploading, CZ rings, <Z> read-out, 6 <= n <= 10.
+// n = 6, 7 (the reference's own `QIDDM_LL_noise(784, 6, 14, 2)`, src/mnist_exm.py:46): the state fits one wavefront
+// (k = (r << 6) | lane), so every wave runs the whole circuit on its own copy -- no wave-bit exchange, no barrier
+// inside the layer loop -- and the four waves still share the two linears.
 #pragma once
 #include "qsim_adjoint.h"  // wave_reduce8_into
 #include "qsim_fused.h"
@@ -33,11 +36,16 @@ struct QuadScalars {
 //     t_hi[l][k >> 8]   (register bits 8.., n > 8; the CZ sign then comes from the parity bits as before)
 // The diagonal after the last RY layer does not reach |amplitude|^2 and is dropped.  An RY has real entries:
 // a lane-bit gate is  c * own +- s * partner  (one packed multiply, one packed FMA, two floats of gate data).
+// index bits owned by the thread number: lane bits 0..5, plus the wave bits 6, 7 from 8 qubits on
+template <int N>
+__host__ __device__ constexpr int quad_thread_bits() { return N >= 8 ? 8 : 6; }
+
 template <typename T, int N>
 struct QuadSmem {
-  static constexpr int R = 1 << (N - 8);
+  static constexpr int R = 1 << (N - quad_thread_bits<N>());
   __host__ __device__ static size_t ry_bytes(int64_t n_rot) { return (size_t)n_rot * 2 * sizeof(T); }
-  __host__ __device__ static size_t tlo_bytes(int64_t n_rot) { return (size_t)(n_rot / N) * 256 * 2 * sizeof(T); }
+  static constexpr int TL = 1 << quad_thread_bits<N>();  // phase-table entries per layer (one per thread-owned index)
+  __host__ __device__ static size_t tlo_bytes(int64_t n_rot) { return (size_t)(n_rot / N) * TL * 2 * sizeof(T); }
   __host__ __device__ static size_t thi_bytes(int64_t n_rot) {
     return ((size_t)(n_rot / N) * R * 2 * sizeof(T) + 15) / 16 * 16;
   }
@@ -76,7 +84,7 @@ __device__ __forceinline__ void ry_regs(V2<T> (&a)[R], T c, T s) {
 template <typename T, int N>
 struct QuadLayerData {
   using C = V2<T>;
-  static constexpr int R = 1 << (N - 8);
+  static constexpr int R = 1 << (N - quad_thread_bits<N>());
   C ry[N];     // (cos, sin)(theta / 2) per WIRE
   C tlo;       // this thread's phase
   C thi[R];    // register-bit phases (n > 8)
@@ -86,7 +94,8 @@ struct QuadLayerData {
                                        int prev_range, int tid) {
 #pragma unroll
     for (int w = 0; w < N; ++w) ry[w] = s_ry[layer * N + w];
-    tlo = s_tlo[layer * 256 + tid];
+    constexpr int TL = 1 << quad_thread_bits<N>();
+    tlo = s_tlo[layer * TL + (tid & (TL - 1))];
     if constexpr (R > 1) {
 #pragma unroll
       for (int r = 0; r < R; ++r) thi[r] = s_thi[layer * R + r];
@@ -102,7 +111,8 @@ __device__ __forceinline__ void quad_build_tables(const double* __restrict__ ang
                                                   int sel_layers, V2<T>* ry, V2<T>* tlo, V2<T>* thi, double* alpha,
                                                   int tid, uint32_t kbase) {
   using C = V2<T>;
-  constexpr int R = 1 << (N - 8);
+  constexpr int TB = quad_thread_bits<N>();
+  constexpr int R = 1 << (N - TB);
   const int n_layers_all = n_rot / N;
   for (int g = tid; g < n_rot; g += 256) {
     double c, sn;
@@ -118,7 +128,7 @@ __device__ __forceinline__ void quad_build_tables(const double* __restrict__ ang
     // RZ(alpha) = diag(e^{-i alpha/2}, e^{+i alpha/2}): the phases of all wires add up to one angle
     double ang = 0.0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < TB; ++q) {
       const double al = alpha[l * N + (N - 1 - q)];
       ang += ((kbase >> q) & 1u) ? 0.5 * al : -0.5 * al;
     }
@@ -130,15 +140,16 @@ __device__ __forceinline__ void quad_build_tables(const double* __restrict__ ang
         sn = -sn;
       }
     }
-    tlo[l * 256 + tid] = C{(T)c, (T)sn};
+    constexpr int TL = 1 << TB;
+    if (tid < TL) tlo[l * TL + tid] = C{(T)c, (T)sn};
   }
   if constexpr (R > 1) {
     for (int i = tid; i < n_layers_all * R; i += 256) {
       const int l = i / R, r = i % R;
       double ang = 0.0;
 #pragma unroll
-      for (int j = 0; j < N - 8; ++j) {
-        const double al = alpha[l * N + (N - 1 - (8 + j))];
+      for (int j = 0; j < N - TB; ++j) {
+        const double al = alpha[l * N + (N - 1 - (TB + j))];
         ang += ((r >> j) & 1) ? 0.5 * al : -0.5 * al;
       }
       double c, sn;
@@ -157,7 +168,7 @@ __global__ __launch_bounds__(256) void quad_tables_kernel(const double* __restri
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n_rot = p.n_rounds * p.n_blocks * p.sel_layers * N;
   const int tid = threadIdx.x;
-  const uint32_t kbase = ((uint32_t)(tid >> 6) << 6) | (uint32_t)logical_lane(tid & 63);
+  const uint32_t kbase = (quad_thread_bits<N>() == 8 ? ((uint32_t)(tid >> 6) << 6) : 0u) | (uint32_t)logical_lane(tid & 63);
   unsigned char* base = reinterpret_cast<unsigned char*>(tables);
   C* ry = reinterpret_cast<C*>(base);
   C* tlo = reinterpret_cast<C*>(base + (QS::ry_bytes(n_rot) + 15) / 16 * 16);
@@ -171,9 +182,10 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
     const double* __restrict__ x, const double* __restrict__ wd, const double* __restrict__ bd,
     const double* __restrict__ angles, const double* __restrict__ wu, const double* __restrict__ bu,
     double* __restrict__ y, const T* __restrict__ tables, const QuadScalars d, const KScalars p) {
-  static_assert(N >= 8 && N <= 10, "quad layout: 8..10 qubits");
+  static_assert(N >= 6 && N <= 10, "quad layout: 6..10 qubits");
   using C = V2<T>;
-  constexpr int R = 1 << (N - 8);
+  constexpr int TB = quad_thread_bits<N>();  // 8: index bits 6, 7 live in the wave number; 6: every wave holds a copy
+  constexpr int R = 1 << (N - TB);
   // PPT pixels per thread (in/out features <= 256 * PPT) stay in registers across the steps
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n_rot = p.n_rounds * p.n_blocks * p.sel_layers * N;
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
   // ---- staging: RY coefficients and phase tables (built here, or copied when the caller prepared them once per
   //      weights with quad_tables_kernel), CZ parity bits ------------------------------------------------------
   const int layers_per_round = p.n_blocks * p.sel_layers;
-  const uint32_t kbase = ((uint32_t)wv << 6) | (uint32_t)llane;  // index bits 0..7 of this thread
+  const uint32_t kbase = (TB == 8 ? ((uint32_t)wv << 6) : 0u) | (uint32_t)llane;  // index bits 0..TB-1 of this thread
   if (tables != nullptr) {
     const int n_t = (int)((QS::ry_bytes(n_rot) + 15) / 16 * 16 + QS::tlo_bytes(n_rot) + QS::thi_bytes(n_rot)) / (int)sizeof(T);
     T* dst = reinterpret_cast<T*>(s_ry);
@@ -233,14 +245,14 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
     for (int rr = 1; rr < N; ++rr) {
       uint32_t bits = 0;
 #pragma unroll
-      for (int r = 0; r < R; ++r) bits |= cz_ring_parity<N>(((uint32_t)r << 8) | kbase, rr) << r;
+      for (int r = 0; r < R; ++r) bits |= cz_ring_parity<N>(((uint32_t)r << TB) | kbase, rr) << r;
       s_cz[(rr - 1) * 256 + tid] = bits;
     }
   }
   // +-1 by this thread's index bit: the sign of sin in its row of RY
   T pm[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) pm[q] = ((kbase >> q) & 1u) ? (T)1 : (T)-1;
+  for (int q = 0; q < 8; ++q) pm[q] = ((kbase >> q) & 1u) ? (T)1 : (T)-1;  // (bits 6, 7 unused when TB == 6)
   const double bd_mine = (bd && tid < N) ? bd[tid] : 0.0;
   __syncthreads();
   if (stamp) d.stamps[1] = __builtin_amdgcn_s_memtime();
@@ -305,7 +317,7 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
         {
           T fr = 1, fi = 0;
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {  // lane bits 0..5 and wave bits 6, 7
+          for (int q = 0; q < TB; ++q) {  // lane bits 0..5 (and wave bits 6, 7)
             const T c = (T)s_cs[N - 1 - q];
             const T si = ((kbase >> q) & 1u) ? (T)s_sn[N - 1 - q] : -(T)s_sn[N - 1 - q];
             const T nr = fr * c - fi * si;
@@ -314,8 +326,8 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
           }
           dx[0] = C{fr, fi};
 #pragma unroll
-          for (int j = 0; j < N - 8; ++j) {
-            const T c = (T)s_cs[N - 1 - (8 + j)], s = (T)s_sn[N - 1 - (8 + j)];
+          for (int j = 0; j < N - TB; ++j) {
+            const T c = (T)s_cs[N - 1 - (TB + j)], s = (T)s_sn[N - 1 - (TB + j)];
 #pragma unroll
             for (int r = 0; r < (1 << j); ++r) {
               const C dd = dx[r];
@@ -345,37 +357,44 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
             a[r] = v;
           }
           // ---- RY on every wire: wire w <-> index bit N-1-w.  Register bits, lane bits, then the wave pair ----
-          if constexpr (N > 8) ry_regs<1, T, R>(a, cur.ry[N - 1 - 8].x, cur.ry[N - 1 - 8].y);
-          if constexpr (N > 9) ry_regs<2, T, R>(a, cur.ry[N > 9 ? N - 1 - 9 : 0].x, cur.ry[N > 9 ? N - 1 - 9 : 0].y);
+          if constexpr (N > TB) ry_regs<1, T, R>(a, cur.ry[N - 1 - TB].x, cur.ry[N - 1 - TB].y);
+          if constexpr (N > TB + 1)
+            ry_regs<2, T, R>(a, cur.ry[N > TB + 1 ? N - 2 - TB : 0].x, cur.ry[N > TB + 1 ? N - 2 - TB : 0].y);
           ry_lane<5, T, R>(a, cur.ry[N - 1 - 5].x, cur.ry[N - 1 - 5].y * pm[5], lane);
           ry_lane<4, T, R>(a, cur.ry[N - 1 - 4].x, cur.ry[N - 1 - 4].y * pm[4], lane);
           ry_lane<3, T, R>(a, cur.ry[N - 1 - 3].x, cur.ry[N - 1 - 3].y * pm[3], lane);
           ry_lane<2, T, R>(a, cur.ry[N - 1 - 2].x, cur.ry[N - 1 - 2].y * pm[2], lane);
           ry_lane<1, T, R>(a, cur.ry[N - 1 - 1].x, cur.ry[N - 1 - 1].y * pm[1], lane);
           ry_lane<0, T, R>(a, cur.ry[N - 1 - 0].x, cur.ry[N - 1 - 0].y * pm[0], lane);
-          // ---- bits 6 and 7 together: new = sum_j M[wv][wv ^ j] * amp(wave wv ^ j),  M = RY_7 (x) RY_6 (real) ----
-          const T c6 = cur.ry[N - 1 - 6].x, t6 = cur.ry[N - 1 - 6].y * pm[6];
-          const T c7 = cur.ry[N - 1 - 7].x, t7 = cur.ry[N - 1 - 7].y * pm[7];
-          const T k0 = c7 * c6, k1 = c7 * t6, k2 = t7 * c6, k3 = t7 * t6;
-          C* buf = s_slab + (size_t)xbuf_parity * (4 * R * kWave);
-          xbuf_parity ^= 1;
+          if constexpr (TB == 8) {
+            // ---- bits 6 and 7 together: new = sum_j M[wv][wv ^ j] * amp(wave wv ^ j),  M = RY_7 (x) RY_6 (real) ----
+            const T c6 = cur.ry[N - 1 - 6].x, t6 = cur.ry[N - 1 - 6].y * pm[6];
+            const T c7 = cur.ry[N - 1 - 7].x, t7 = cur.ry[N - 1 - 7].y * pm[7];
+            const T k0 = c7 * c6, k1 = c7 * t6, k2 = t7 * c6, k3 = t7 * t6;
+            C* buf = s_slab + (size_t)xbuf_parity * (4 * R * kWave);
+            xbuf_parity ^= 1;
 #pragma unroll
-          for (int r = 0; r < R; ++r) buf[(wv * R + r) * kWave + lane] = a[r];
-          // next layer's data: in flight across the barrier
-          {
+            for (int r = 0; r < R; ++r) buf[(wv * R + r) * kWave + lane] = a[r];
+            // next layer's data: in flight across the barrier
+            {
+              const int l_next = round * layers_per_round + li + 1;
+              cur.load(s_ry, s_tlo, s_thi, s_cz, l_next < n_layers_all ? l_next : 0, s % (N - 1), tid);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              const C p1 = buf[((wv ^ 1) * R + r) * kWave + lane];
+              const C p2 = buf[((wv ^ 2) * R + r) * kWave + lane];
+              const C p3 = buf[((wv ^ 3) * R + r) * kWave + lane];
+              C o = bcast<T>(k0) * a[r];
+              o = __builtin_elementwise_fma(bcast<T>(k1), p1, o);
+              o = __builtin_elementwise_fma(bcast<T>(k2), p2, o);
+              a[r] = __builtin_elementwise_fma(bcast<T>(k3), p3, o);
+            }
+          } else {
+            // the whole state is in this wave: nothing to exchange, only the next layer's data to fetch
             const int l_next = round * layers_per_round + li + 1;
             cur.load(s_ry, s_tlo, s_thi, s_cz, l_next < n_layers_all ? l_next : 0, s % (N - 1), tid);
-          }
-          __syncthreads();
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const C p1 = buf[((wv ^ 1) * R + r) * kWave + lane];
-            const C p2 = buf[((wv ^ 2) * R + r) * kWave + lane];
-            const C p3 = buf[((wv ^ 3) * R + r) * kWave + lane];
-            C o = bcast<T>(k0) * a[r];
-            o = __builtin_elementwise_fma(bcast<T>(k1), p1, o);
-            o = __builtin_elementwise_fma(bcast<T>(k2), p2, o);
-            a[r] = __builtin_elementwise_fma(bcast<T>(k3), p3, o);
           }
         }
         // (the ring and the RZ(omega) after the last RY layer are diagonal: they do not reach |amplitude|^2)
@@ -386,7 +405,7 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const T pr = a[r].x * a[r].x + a[r].y * a[r].y;
-          const uint32_t k = ((uint32_t)r << 8) | kbase;
+          const uint32_t k = ((uint32_t)r << TB) | kbase;
 #pragma unroll
           for (int w = 0; w < N; ++w) ez[w] += ((k >> (N - 1 - w)) & 1u) ? -pr : pr;
         }
@@ -405,7 +424,8 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
         }
         __syncthreads();
         if (tid < N) {
-          const double e = s_part[tid] + s_part[16 + tid] + s_part[32 + tid] + s_part[48 + tid];
+          // TB == 6: every wave summed the whole (replicated) state -- take wave 0's
+          const double e = TB == 8 ? s_part[tid] + s_part[16 + tid] + s_part[32 + tid] + s_part[48 + tid] : s_part[tid];
           s_xs[tid] = e * p.enc_scale;  // next round's angles
           s_cs[tid] = e;                // plain <Z_w> for linear_up (s_cs is rebuilt next round)
         }
