@@ -107,3 +107,32 @@ def test_c5_16_qubits_batch_1024():
     wp = (torch.randn(probs.angles_shape, dtype=torch.float64) * 0.4).to(DEV)
     p = _fwd(probs, x[:256], wp)
     assert torch.allclose(p.sum(1), torch.ones(256, device=DEV), atol=5e-5)
+
+
+@pytest.mark.parametrize("c_in,c_out,k,pad", [(16, 8, 3, 1), (32, 16, 3, 1), (16, 8, 1, 0)])
+def test_qconv_training_routes_agree_at_full_resolution(c_in, c_out, k, pad):
+    """A unet_simple layer at 28 x 28, 64 net samples (50 176 circuits -- beyond what the oracle finishes in seconds):
+    the float32 unitary route (GEMM forward, thin-product backward, one adjoint sweep per channel) against the
+    float64 per-pixel route (fused circuit launch, adjoint sweep per output pixel, fold) -- two independent
+    algorithms for the same layer -- on outputs, weight gradients and input gradients."""
+    from qiddm_amd import nn, set_default_precision
+    torch.manual_seed(21)
+    layer = nn.QConv2d(c_in, c_out, k, pad, 3).cuda().train()
+    x = torch.rand(64, c_in, 28, 28, dtype=torch.float64, device="cuda")
+    g = torch.randn(64, c_out, 28, 28, dtype=torch.float64, device="cuda")
+    res = {}
+    for precision in ("f32", "f64"):
+        set_default_precision(precision)
+        try:
+            layer.weights.grad = None
+            xi = x.clone().requires_grad_(True)
+            y = layer(xi)
+            (y * g).sum().backward()
+            res[precision] = (y.detach(), layer.weights.grad.clone(), xi.grad.clone())
+        finally:
+            set_default_precision("f32")
+    (y32, gw32, gx32), (y64, gw64, gx64) = res["f32"], res["f64"]
+    assert (y32 - y64).abs().max().item() < 2e-4
+    assert (gw32 - gw64).abs().max().item() < 1e-3 * max(gw64.abs().max().item(), 1.0)
+    assert (gx32 - gx64).abs().max().item() < 1e-3 * max(gx64.abs().max().item(), 1.0)
+    assert 0.0 <= y32.min().item() and y32.max().item() <= 1.0
