@@ -220,7 +220,7 @@ int qiddm_dense_forward(const qiddm_circuit_t *circ, const double *x, int64_t ba
  * in ONE launch, net = linear_down -> circuit rounds -> linear_up as in qiddm_dense_forward.
  * y: (n_steps, batch, out_features) float64, y[s] = the image after step s+1 (row stride y_ld,
  * step stride y_step_stride).  n_steps > 1 needs out_features == in_features.  Four wavefronts own
- * one sample (qsim_quad.h): supported for 6 <= n_qubits <= 10 (below 8 every wavefront runs the circuit on its own copy of the state), QIDDM_IMP_CZ, QIDDM_ENC_RZ,
+ * one sample (qsim_quad.h): supported for 2 <= n_qubits <= 10 (below 8 every wavefront runs the circuit on its own copy of the state), QIDDM_IMP_CZ, QIDDM_ENC_RZ,
  * QIDDM_MEAS_EXPZ, features <= 2048; anything else returns QIDDM_ERR_UNSUPPORTED (loop over
  * qiddm_dense_forward instead).                                                               */
 int qiddm_dense_sample(const qiddm_circuit_t *circ, const double *x, int64_t batch, int64_t x_ld,

@@ -264,6 +264,10 @@ int dispatch_qconv(int n, const double* x, const double* angles, double* y, cons
 template <typename T>
 size_t quad_lds_bytes(int n, int64_t n_rot) {
   switch (n) {
+    case 2: return qiddm::QuadSmem<T, 2>::bytes(n_rot);
+    case 3: return qiddm::QuadSmem<T, 3>::bytes(n_rot);
+    case 4: return qiddm::QuadSmem<T, 4>::bytes(n_rot);
+    case 5: return qiddm::QuadSmem<T, 5>::bytes(n_rot);
     case 6: return qiddm::QuadSmem<T, 6>::bytes(n_rot);
     case 7: return qiddm::QuadSmem<T, 7>::bytes(n_rot);
     case 8: return qiddm::QuadSmem<T, 8>::bytes(n_rot);
@@ -273,7 +277,7 @@ size_t quad_lds_bytes(int n, int64_t n_rot) {
 }
 
 bool quad_supported(const qiddm_circuit_t* c, int64_t in_features, int64_t out_features) {
-  if (!(c->n_qubits >= 6 && c->n_qubits <= 10 && c->imprimitive == QIDDM_IMP_CZ &&
+  if (!(c->n_qubits >= 2 && c->n_qubits <= 10 && c->imprimitive == QIDDM_IMP_CZ &&
         c->encoding == QIDDM_ENC_RZ && c->measure == QIDDM_MEAS_EXPZ && in_features <= 2048 && out_features <= 2048))
     return false;
   // its per-layer phase tables must fit in LDS (deep float64 circuits at n = 10 do not)
@@ -320,6 +324,10 @@ size_t quad_tables_bytes_n(int64_t n_rot) {
 template <typename T>
 size_t quad_tables_bytes(int n, int64_t n_rot) {
   switch (n) {
+    case 2: return quad_tables_bytes_n<T, 2>(n_rot);
+    case 3: return quad_tables_bytes_n<T, 3>(n_rot);
+    case 4: return quad_tables_bytes_n<T, 4>(n_rot);
+    case 5: return quad_tables_bytes_n<T, 5>(n_rot);
     case 6: return quad_tables_bytes_n<T, 6>(n_rot);
     case 7: return quad_tables_bytes_n<T, 7>(n_rot);
     case 8: return quad_tables_bytes_n<T, 8>(n_rot);
@@ -342,6 +350,10 @@ int dispatch_quad(int n, const double* x, const double* wd, const double* bd, co
                   const double* wu, const double* bu, double* y, const void* tables, const qiddm::QuadScalars& d,
                   const qiddm::KScalars& p, hipStream_t st) {
   switch (n) {
+    case 2: return launch_quad<T, 2>(x, wd, bd, angles, wu, bu, y, tables, d, p, st);
+    case 3: return launch_quad<T, 3>(x, wd, bd, angles, wu, bu, y, tables, d, p, st);
+    case 4: return launch_quad<T, 4>(x, wd, bd, angles, wu, bu, y, tables, d, p, st);
+    case 5: return launch_quad<T, 5>(x, wd, bd, angles, wu, bu, y, tables, d, p, st);
     case 6: return launch_quad<T, 6>(x, wd, bd, angles, wu, bu, y, tables, d, p, st);
     case 7: return launch_quad<T, 7>(x, wd, bd, angles, wu, bu, y, tables, d, p, st);
     case 8: return launch_quad<T, 8>(x, wd, bd, angles, wu, bu, y, tables, d, p, st);
@@ -1024,7 +1036,7 @@ int qiddm_dense_sample(const qiddm_circuit_t* c, const double* x, int64_t batch,
   if (batch < 0 || n_steps < 0) return fail(QIDDM_ERR_INVALID, "negative batch / n_steps");
   if (in_features < 1 || out_features < 1) return fail(QIDDM_ERR_INVALID, "bad feature counts");
   if (!quad_supported(c, in_features, out_features))
-    return fail(QIDDM_ERR_UNSUPPORTED, "fused sampling loop: needs 6 <= n <= 10, CZ, RZ encoding, <Z>, "
+    return fail(QIDDM_ERR_UNSUPPORTED, "fused sampling loop: needs 2 <= n <= 10, CZ, RZ encoding, <Z>, "
                 "features <= 2048");
   if (post_mode != 0 && post_mode != 1) return fail(QIDDM_ERR_INVALID, "post_mode must be 0 or 1");
   if ((post_mode == 1 || n_steps > 1) && in_features != out_features)
@@ -1073,6 +1085,10 @@ int qiddm_dense_sample_prepare(const qiddm_circuit_t* c, const double* angles, v
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool f32 = c->dtype == QIDDM_F32;
   switch (c->n_qubits) {
+    case 2: return f32 ? launch_quad_tables<float, 2>(angles, tables, p, n_rot, st) : launch_quad_tables<double, 2>(angles, tables, p, n_rot, st);
+    case 3: return f32 ? launch_quad_tables<float, 3>(angles, tables, p, n_rot, st) : launch_quad_tables<double, 3>(angles, tables, p, n_rot, st);
+    case 4: return f32 ? launch_quad_tables<float, 4>(angles, tables, p, n_rot, st) : launch_quad_tables<double, 4>(angles, tables, p, n_rot, st);
+    case 5: return f32 ? launch_quad_tables<float, 5>(angles, tables, p, n_rot, st) : launch_quad_tables<double, 5>(angles, tables, p, n_rot, st);
     case 6: return f32 ? launch_quad_tables<float, 6>(angles, tables, p, n_rot, st) : launch_quad_tables<double, 6>(angles, tables, p, n_rot, st);
     case 7: return f32 ? launch_quad_tables<float, 7>(angles, tables, p, n_rot, st) : launch_quad_tables<double, 7>(angles, tables, p, n_rot, st);
     case 8: return f32 ? launch_quad_tables<float, 8>(angles, tables, p, n_rot, st) : launch_quad_tables<double, 8>(angles, tables, p, n_rot, st);

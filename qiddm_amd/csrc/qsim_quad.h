@@ -10,10 +10,11 @@
 // threads, and the whole sampling loop x <- net(x) (reference src/models.py:124-136) can run for
 // `n_steps` iterations inside the launch with x held in registers.
 //
-// Restricted to what the dense nets need: RZ data re-uploading, CZ rings, <Z> read-out, 6 <= n <= 10.
+// Restricted to what the dense nets need: RZ data re-uploading, CZ rings, <Z> read-out, 2 <= n <= 10.
 // n = 6, 7 (the reference's own `QIDDM_LL_noise(784, 6, 14, 2)`, src/mnist_exm.py:46): the state fits one wavefront
 // (k = (r << 6) | lane), so every wave runs the whole circuit on its own copy -- no wave-bit exchange, no barrier
-// inside the layer loop -- and the four waves still share the two linears.
+// inside the layer loop -- and the four waves still share the two linears.  Below 6 qubits (C1's 4-qubit nets) the
+// spare lane bits hold further copies of the state.
 #pragma once
 #include "qsim_adjoint.h"  // wave_reduce8_into
 #include "qsim_fused.h"
@@ -38,7 +39,14 @@ struct QuadScalars {
 // a lane-bit gate is  c * own +- s * partner  (one packed multiply, one packed FMA, two floats of gate data).
 // index bits owned by the thread number: lane bits 0..5, plus the wave bits 6, 7 from 8 qubits on
 template <int N>
-__host__ __device__ constexpr int quad_thread_bits() { return N >= 8 ? 8 : 6; }
+__host__ __device__ constexpr int quad_thread_bits() { return N >= 8 ? 8 : (N >= 6 ? 6 : N); }
+// index bits of a thread: wave bits (8+ qubits) and the low LOGICAL lane bits; below 6 qubits the remaining lane bits
+// (like the waves below 8) hold further copies of the state
+template <int N>
+__device__ __forceinline__ uint32_t quad_kbase(int wv, int llane) {
+  constexpr int TB = quad_thread_bits<N>();
+  return (TB == 8 ? ((uint32_t)wv << 6) : 0u) | ((uint32_t)llane & ((1u << (TB < 6 ? TB : 6)) - 1u));
+}
 
 template <typename T, int N>
 struct QuadSmem {
@@ -95,7 +103,7 @@ struct QuadLayerData {
 #pragma unroll
     for (int w = 0; w < N; ++w) ry[w] = s_ry[layer * N + w];
     constexpr int TL = 1 << quad_thread_bits<N>();
-    tlo = s_tlo[layer * TL + (tid & (TL - 1))];
+    tlo = s_tlo[layer * TL + (quad_thread_bits<N>() < 6 ? (int)quad_kbase<N>(0, logical_lane(tid & 63)) : (tid & (TL - 1)))];
     if constexpr (R > 1) {
 #pragma unroll
       for (int r = 0; r < R; ++r) thi[r] = s_thi[layer * R + r];
@@ -141,7 +149,14 @@ __device__ __forceinline__ void quad_build_tables(const double* __restrict__ ang
       }
     }
     constexpr int TL = 1 << TB;
-    if (tid < TL) tlo[l * TL + tid] = C{(T)c, (T)sn};
+    // one writer per entry: thread tid owns index kbase (== its slot for TB >= 6; below, the first copy writes)
+    if (tid < 64 || TB == 8) {
+      if (TB >= 6) {
+        if (tid < TL) tlo[l * TL + tid] = C{(T)c, (T)sn};
+      } else if ((logical_lane(tid) >> TB) == 0) {
+        tlo[l * TL + (int)kbase] = C{(T)c, (T)sn};
+      }
+    }
   }
   if constexpr (R > 1) {
     for (int i = tid; i < n_layers_all * R; i += 256) {
@@ -168,7 +183,7 @@ __global__ __launch_bounds__(256) void quad_tables_kernel(const double* __restri
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int n_rot = p.n_rounds * p.n_blocks * p.sel_layers * N;
   const int tid = threadIdx.x;
-  const uint32_t kbase = (quad_thread_bits<N>() == 8 ? ((uint32_t)(tid >> 6) << 6) : 0u) | (uint32_t)logical_lane(tid & 63);
+  const uint32_t kbase = quad_kbase<N>(tid >> 6, logical_lane(tid & 63));
   unsigned char* base = reinterpret_cast<unsigned char*>(tables);
   C* ry = reinterpret_cast<C*>(base);
   C* tlo = reinterpret_cast<C*>(base + (QS::ry_bytes(n_rot) + 15) / 16 * 16);
@@ -182,9 +197,9 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
     const double* __restrict__ x, const double* __restrict__ wd, const double* __restrict__ bd,
     const double* __restrict__ angles, const double* __restrict__ wu, const double* __restrict__ bu,
     double* __restrict__ y, const T* __restrict__ tables, const QuadScalars d, const KScalars p) {
-  static_assert(N >= 6 && N <= 10, "quad layout: 6..10 qubits");
+  static_assert(N >= 2 && N <= 10, "quad layout: 2..10 qubits");
   using C = V2<T>;
-  constexpr int TB = quad_thread_bits<N>();  // 8: index bits 6, 7 live in the wave number; 6: every wave holds a copy
+  constexpr int TB = quad_thread_bits<N>();  // 8: index bits 6, 7 live in the wave number; <= 6: every wave holds a copy
   constexpr int R = 1 << (N - TB);
   // PPT pixels per thread (in/out features <= 256 * PPT) stay in registers across the steps
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
   // ---- staging: RY coefficients and phase tables (built here, or copied when the caller prepared them once per
   //      weights with quad_tables_kernel), CZ parity bits ------------------------------------------------------
   const int layers_per_round = p.n_blocks * p.sel_layers;
-  const uint32_t kbase = (TB == 8 ? ((uint32_t)wv << 6) : 0u) | (uint32_t)llane;  // index bits 0..TB-1 of this thread
+  const uint32_t kbase = quad_kbase<N>(wv, llane);  // index bits 0..TB-1 of this thread
   if (tables != nullptr) {
     const int n_t = (int)((QS::ry_bytes(n_rot) + 15) / 16 * 16 + QS::tlo_bytes(n_rot) + QS::thi_bytes(n_rot)) / (int)sizeof(T);
     T* dst = reinterpret_cast<T*>(s_ry);
@@ -360,12 +375,12 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
           if constexpr (N > TB) ry_regs<1, T, R>(a, cur.ry[N - 1 - TB].x, cur.ry[N - 1 - TB].y);
           if constexpr (N > TB + 1)
             ry_regs<2, T, R>(a, cur.ry[N > TB + 1 ? N - 2 - TB : 0].x, cur.ry[N > TB + 1 ? N - 2 - TB : 0].y);
-          ry_lane<5, T, R>(a, cur.ry[N - 1 - 5].x, cur.ry[N - 1 - 5].y * pm[5], lane);
-          ry_lane<4, T, R>(a, cur.ry[N - 1 - 4].x, cur.ry[N - 1 - 4].y * pm[4], lane);
-          ry_lane<3, T, R>(a, cur.ry[N - 1 - 3].x, cur.ry[N - 1 - 3].y * pm[3], lane);
-          ry_lane<2, T, R>(a, cur.ry[N - 1 - 2].x, cur.ry[N - 1 - 2].y * pm[2], lane);
-          ry_lane<1, T, R>(a, cur.ry[N - 1 - 1].x, cur.ry[N - 1 - 1].y * pm[1], lane);
-          ry_lane<0, T, R>(a, cur.ry[N - 1 - 0].x, cur.ry[N - 1 - 0].y * pm[0], lane);
+          if constexpr (N > 5) ry_lane<5, T, R>(a, cur.ry[N > 5 ? N - 1 - 5 : 0].x, cur.ry[N > 5 ? N - 1 - 5 : 0].y * pm[5], lane);
+          if constexpr (N > 4) ry_lane<4, T, R>(a, cur.ry[N > 4 ? N - 1 - 4 : 0].x, cur.ry[N > 4 ? N - 1 - 4 : 0].y * pm[4], lane);
+          if constexpr (N > 3) ry_lane<3, T, R>(a, cur.ry[N > 3 ? N - 1 - 3 : 0].x, cur.ry[N > 3 ? N - 1 - 3 : 0].y * pm[3], lane);
+          if constexpr (N > 2) ry_lane<2, T, R>(a, cur.ry[N > 2 ? N - 1 - 2 : 0].x, cur.ry[N > 2 ? N - 1 - 2 : 0].y * pm[2], lane);
+          if constexpr (N > 1) ry_lane<1, T, R>(a, cur.ry[N > 1 ? N - 1 - 1 : 0].x, cur.ry[N > 1 ? N - 1 - 1 : 0].y * pm[1], lane);
+          if constexpr (N > 0) ry_lane<0, T, R>(a, cur.ry[N > 0 ? N - 1 - 0 : 0].x, cur.ry[N > 0 ? N - 1 - 0 : 0].y * pm[0], lane);
           if constexpr (TB == 8) {
             // ---- bits 6 and 7 together: new = sum_j M[wv][wv ^ j] * amp(wave wv ^ j),  M = RY_7 (x) RY_6 (real) ----
             const T c6 = cur.ry[N - 1 - 6].x, t6 = cur.ry[N - 1 - 6].y * pm[6];
@@ -425,7 +440,9 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
         __syncthreads();
         if (tid < N) {
           // TB == 6: every wave summed the whole (replicated) state -- take wave 0's
-          const double e = TB == 8 ? s_part[tid] + s_part[16 + tid] + s_part[32 + tid] + s_part[48 + tid] : s_part[tid];
+          // (below 6 qubits the wave's 64 lanes summed 2^(6-TB) copies)
+          const double e = TB == 8 ? s_part[tid] + s_part[16 + tid] + s_part[32 + tid] + s_part[48 + tid]
+                                   : s_part[tid] * (1.0 / (double)(1 << (TB < 6 ? 6 - TB : 0)));
           s_xs[tid] = e * p.enc_scale;  // next round's angles
           s_cs[tid] = e;                // plain <Z_w> for linear_up (s_cs is rebuilt next round)
         }

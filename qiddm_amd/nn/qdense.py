@@ -290,7 +290,7 @@ class QNN_noise(_QuantumNet):
 
     def fused_sample_steps(self, x, n_steps, goal, noise_factor=1.0):
         """n_steps bodies of Diffusion.sample in one launch; None when not applicable."""
-        if not (self._fused_rounds_ok() and 6 <= self.hidden_features <= 10):
+        if not (self._fused_rounds_ok() and 2 <= self.hidden_features <= 10):
             return None
         b, c, w, h = x.shape
         circ = self._circuit_descriptor()
@@ -496,7 +496,7 @@ class _QIDDMBase(_QuantumNet):
     def fused_sample_steps(self, x, n_steps, goal, noise_factor=1.0):
         """n_steps bodies of Diffusion.sample in one launch; None when not applicable."""
         if not (self._fused_rounds_ok() and not self._use_pca and hasattr(self, "linear_down")
-                and 6 <= self.hidden_features <= 10 and type(self)._circuit is _QIDDMBase._circuit):
+                and 2 <= self.hidden_features <= 10 and type(self)._circuit is _QIDDMBase._circuit):
             return None
         b, c, w, h = x.shape
         flat = x.reshape(b, -1)

@@ -295,7 +295,8 @@ def test_qconv2d_fused_equals_traced_path(cin, cout, k, pad, hw):
 
 @pytest.mark.parametrize("precision,tol", [("f32", 1e-4), ("f64", 1e-9)])
 @pytest.mark.parametrize("n,N,L,S,P", [(8, 1, 1, 14, 784), (8, 2, 6, 2, 784), (9, 2, 2, 2, 300), (10, 1, 3, 2, 100),
-                                       (6, 2, 14, 2, 784), (6, 1, 1, 14, 784), (7, 2, 3, 2, 300), (7, 1, 1, 8, 64)])
+                                       (6, 2, 14, 2, 784), (6, 1, 1, 14, 784), (7, 2, 3, 2, 300), (7, 1, 1, 8, 64),
+                                       (4, 1, 1, 2, 64), (4, 1, 2, 2, 64), (5, 2, 3, 2, 100), (2, 1, 1, 3, 16), (3, 2, 2, 2, 30)])
 def test_dense_sample_quad_kernel(n, N, L, S, P, precision, tol):
     """qiddm_dense_sample: four wavefronts per sample, several sampling-loop bodies in one launch."""
     from qiddm_amd.circuit import Circuit, dense_sample
