@@ -390,7 +390,7 @@ int qiddm_batchnorm_backward(const double *x, const double *grad_y, int64_t batc
  * value every pad column j >= C kh kw shares.
  *   rows: (C kh kw + 1, 2 row_channels) float32 -- rows[j][c] = Re U[2c,j], rows[j][row_channels + c] = Im U[2c,j],
  *         last row 0.5 sum_{j >= C kh kw} U[2c,j]; zero for c >= out_channels.  row_channels in {8, 16, 32}
- *         (C kh kw <= 510; <= 254 for 32): wider layers return QIDDM_ERR_UNSUPPORTED (use qiddm_qconv_backward).
+ *         (C kh kw <= 510): wider layers return QIDDM_ERR_UNSUPPORTED (use qiddm_qconv_backward or library GEMMs).
  * qiddm_matrix_adjoint: K slabs (-> qiddm_adjoint_finalize) of 2 Re <lambda_s| dU/dangle |psi0_s> summed over
  * `count` (psi0, lambda) pairs of complex128 vectors (count, 2^n, interleaved); circ->dtype QIDDM_F64, gate table
  * of that dtype, 2 <= n_qubits <= 16.                                                                        */

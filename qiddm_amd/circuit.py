@@ -564,9 +564,9 @@ def qconv_unitary_route(n_qubits: int, in_channels: int, kernel_size, out_channe
     if not 2 <= n_qubits <= 12 or 2 * out_channels > 2 ** n_qubits or f > 2 ** n_qubits:
         return None
     co = _row_channels(out_channels)
-    if co is not None and max(kernel_size) <= 15 and f + 1 <= (512 if co <= 16 else 256):
+    if co is not None and max(kernel_size) <= 15 and f + 1 <= 512:
         v_stride = (f + 1) | 1
-        lds = ((f + 1) * 2 * co + 64 * v_stride + 64 * (2 * co + 1) + 4 * 64 * (co + 1) + 8 * 64) * 4 + f * 4
+        lds = ((f + 1) * 2 * co + 64 * v_stride + 64 * (2 * co + 1) + 8 * 64 * (co + 1) + 16 * 64) * 4 + f * 4
         if lds <= 160 * 1024:
             return "thin"
     return "gemm"

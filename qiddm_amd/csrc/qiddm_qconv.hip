@@ -279,14 +279,12 @@ int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch,
     kern = reinterpret_cast<const void*>(qiddm::qconv_train_backward_kernel<CO, J>);              \
   }
   QIDDM_TC_CASE(8, 1)
-  QIDDM_TC_CASE(8, 2)
   QIDDM_TC_CASE(16, 1)
-  QIDDM_TC_CASE(16, 2)
   QIDDM_TC_CASE(32, 1)
 #undef QIDDM_TC_CASE
   if (!kern)
     return fail(QIDDM_ERR_UNSUPPORTED, "unitary-route backward: row_channels=%d with %lld features is outside "
-                "{8,16} x 511 / 32 x 255", row_channels, (long long)f);
+                "{8,16,32} x 511", row_channels, (long long)f);
   if (smem > kMaxLds) return fail(QIDDM_ERR_UNSUPPORTED, "unitary-route backward needs %zu B of LDS", smem);
   if (smem > 48 * 1024) {
     const hipError_t ea = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);

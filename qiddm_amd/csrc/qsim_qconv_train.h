@@ -32,34 +32,36 @@ struct TrainConv {
   float post_scale;   // D / 2
 };
 
-constexpr int kTcThreads = 256;
-constexpr int kTcTile = 64;  // output pixels per tile: lane = pixel, the four waves split the feature columns
+constexpr int kTcWaves = 8;                  // wavefronts per workgroup: they split the feature columns of a tile
+constexpr int kTcThreads = 64 * kTcWaves;
+constexpr int kTcTile = 64;  // output pixels per tile: lane = pixel
 
 __host__ __device__ inline int tc_v_stride(int F) { return (F + 1) | 1; }  // odd: conflict-free row writes
 template <int CO>
 __host__ __device__ inline size_t tc_lds_bytes(int F) {
-  // rows table, v^ tile, W2 tile, cross-wave partials [4][64][CO + 1], per-pixel scalars [2][4][64], tap table
+  // rows table, v^ tile, W2 tile, cross-wave partials [waves][64][CO + 1], per-pixel scalars [2][waves][64], taps
   return ((size_t)(F + 1) * 2 * CO + (size_t)kTcTile * tc_v_stride(F) + (size_t)kTcTile * (2 * CO + 1) +
-          (size_t)4 * kTcTile * (CO + 1) + (size_t)8 * kTcTile) * sizeof(float) +
+          (size_t)kTcWaves * kTcTile * (CO + 1) + (size_t)2 * kTcWaves * kTcTile) * sizeof(float) +
          (size_t)F * sizeof(uint32_t);
 }
 
 template <int CO, int JCH>
-__global__ __launch_bounds__(kTcThreads) void qconv_train_backward_kernel(const double* __restrict__ x,
+__global__ __launch_bounds__(kTcThreads, 1) void qconv_train_backward_kernel(const double* __restrict__ x,
                                                                           const double* __restrict__ gy,
                                                                           const float* __restrict__ rt,
                                                                           float* __restrict__ gfeat_t,
                                                                           float* __restrict__ hpart,
                                                                           const TrainConv tc) {
-  constexpr int K2 = 2 * CO, WS = K2 + 1, PS = CO + 1, CQ = CO / 4;
+  constexpr int K2 = 2 * CO, WS = K2 + 1, PS = CO + 1, NW = kTcWaves, CQ = CO / NW;
+  static_assert(CO % NW == 0, "every wavefront owns CO / waves output channels");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int F = tc.F, FS = tc_v_stride(F);
   float* s_rt = reinterpret_cast<float*>(smem_raw);  // [(F + 1)][K2]
   float* s_v = s_rt + (size_t)(F + 1) * K2;          // [kTcTile][FS]
   float* s_w = s_v + (size_t)kTcTile * FS;           // [kTcTile][WS]
-  float* s_part = s_w + (size_t)kTcTile * WS;        // [4][kTcTile][PS]
-  float* s_sc = s_part + (size_t)4 * kTcTile * PS;   // [2][4][kTcTile]: norm^2 partials, dot partials
-  uint32_t* s_tap = reinterpret_cast<uint32_t*>(s_sc + 8 * kTcTile);  // [F]: offset | di << 24 | dj << 28
+  float* s_part = s_w + (size_t)kTcTile * WS;        // [NW][kTcTile][PS]
+  float* s_sc = s_part + (size_t)NW * kTcTile * PS;  // [2][NW][kTcTile]: norm^2 partials, dot partials
+  uint32_t* s_tap = reinterpret_cast<uint32_t*>(s_sc + 2 * NW * kTcTile);  // [F]: offset | di << 24 | dj << 28
   const int tid = threadIdx.x, q = tid >> 6, lane = tid & 63;
   for (int i = tid; i < (F + 1) * K2; i += kTcThreads) s_rt[i] = rt[i];
   for (int f = tid; f < F; f += kTcThreads) {
@@ -72,9 +74,9 @@ __global__ __launch_bounds__(kTcThreads) void qconv_train_backward_kernel(const 
   for (int jc = 0; jc < JCH; ++jc)
 #pragma unroll
     for (int cc = 0; cc < K2; ++cc) acc[jc][cc] = 0.f;
-  // this wave's quarter of the feature columns
-  const int jq = (F + 3) / 4;
-  const int j_lo = q * jq, j_hi = (j_lo + jq < F) ? j_lo + jq : F;
+  // this wave's share of the feature columns
+  const int jq = (F + NW - 1) / NW;
+  const int j_lo = q * jq < F ? q * jq : F, j_hi = (j_lo + jq < F) ? j_lo + jq : F;
 
   const int64_t pixels = (int64_t)tc.Ho * tc.Wo;
   const int64_t tiles = (tc.M + kTcTile - 1) / kTcTile;
@@ -121,13 +123,14 @@ __global__ __launch_bounds__(kTcThreads) void qconv_train_backward_kernel(const 
         for (int i = 0; i < CQ; ++i) {
           float t = 0.f;
 #pragma unroll
-          for (int w = 0; w < 4; ++w) t += s_part[((size_t)w * kTcTile + lane) * PS + q * CQ + i];
+          for (int w = 0; w < NW; ++w) t += s_part[((size_t)w * kTcTile + lane) * PS + q * CQ + i];
           mine[half * CQ + i] = t;
         }
         __syncthreads();
       }
-      const float nrm2 = tc.pad_norm2 + s_sc[lane] + s_sc[kTcTile + lane] + s_sc[2 * kTcTile + lane] +
-                         s_sc[3 * kTcTile + lane];
+      float nrm2 = tc.pad_norm2;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) nrm2 += s_sc[w * kTcTile + lane];
       const float inv = 1.0f / sqrtf(nrm2);
       // ---- this thread's channels: a, t, W2 = t (Re a, Im a) -> s_w; its share of dot = 2 sum t |a|^2 ------------------
       const double* __restrict__ gpix = gy + (size_t)b * tc.C_out * pixels + pix;
@@ -144,11 +147,12 @@ __global__ __launch_bounds__(kTcThreads) void qconv_train_backward_kernel(const 
         s_w[lane * WS + c] = t * ar;
         s_w[lane * WS + CO + c] = t * ai;
       }
-      s_sc[4 * kTcTile + q * kTcTile + lane] = dotp;
+      s_sc[(NW + q) * kTcTile + lane] = dotp;
       __syncthreads();
       // ---- feature gradients over this wave's columns; s_v becomes v^ ------------------------------------------------
-      const float dot = s_sc[4 * kTcTile + lane] + s_sc[5 * kTcTile + lane] + s_sc[6 * kTcTile + lane] +
-                        s_sc[7 * kTcTile + lane];
+      float dot = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) dot += s_sc[(NW + w) * kTcTile + lane];
 #pragma unroll
       for (int cc = 0; cc < K2; ++cc) a[cc] = s_w[lane * WS + cc];
       for (int j = j_lo; j < j_hi; ++j) {
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(kTcThreads) void qconv_train_backward_kernel(const 
         for (int cc = 0; cc < K2; ++cc) sacc = fmaf(a[cc], r[cc], sacc);
         if (valid) gfeat_t[(size_t)j * tc.M + m] = (2.0f * sacc - vh * dot) * inv;
       }
-      if (q == 3) s_v[lane * FS + F] = 0.5f * inv;  // the value every pad column holds
+      if (q == NW - 1) s_v[lane * FS + F] = 0.5f * inv;  // the value every pad column holds
     }
     __syncthreads();
     // ---- h += W2^T v^ over the tile: thread = feature column -------------------------------------------------------------
