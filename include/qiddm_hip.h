@@ -385,7 +385,7 @@ int qiddm_batchnorm_backward(const double *x, const double *grad_y, int64_t batc
  *     dL/dv^_mj = 2 Re sum_c t_mc conj(a_mc) U[2c,j]   -> through the normalisation and the fold -> grad_x
  *     dL/dangle = 2 Re sum_c <e_2c| dU/dangle |h_c>,   h_c[j] = sum_m t_mc conj(a_mc) v^_mj
  * qiddm_qconv_train_backward computes a, dL/dv (stored transposed, (C kh kw, M) float32, then folded into grad_x
- * unless NULL) and per-workgroup partial sums of h:  h_partials (qiddm_qconv_train_partials, 2 row_channels,
+ * unless NULL) and partial sums of h:  h_partials (qiddm_qconv_train_partials(..., C kh kw), 2 row_channels,
  * C kh kw + 1) float32 with  h_c[j] = sum_p hp[p][c][j] - i sum_p hp[p][row_channels + c][j];  column C kh kw is the
  * value every pad column j >= C kh kw shares.
  *   rows: (C kh kw + 1, 2 row_channels) float32 -- rows[j][c] = Re U[2c,j], rows[j][row_channels + c] = Im U[2c,j],
@@ -407,7 +407,7 @@ int qiddm_qconv_train_vectors(int32_t n_qubits, const float *h_partials, int64_t
 int qiddm_qconv_fold_features(const float *grad_features_t, int64_t batch, int64_t in_channels, int64_t height,
                               int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, double *grad_x,
                               void *stream);
-int64_t qiddm_qconv_train_partials(int64_t batch, int64_t height_out, int64_t width_out);
+int64_t qiddm_qconv_train_partials(int64_t batch, int64_t height_out, int64_t width_out, int64_t features);
 int qiddm_qconv_train_backward(int32_t n_qubits, const double *x, int64_t batch, int64_t in_channels,
                                int64_t height, int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
                                const double *grad_y, int64_t out_channels, const float *rows, int32_t row_channels,

@@ -157,7 +157,7 @@ def _declare(lib):
     lib.qiddm_qconv_train_vectors.restype = ctypes.c_int
     lib.qiddm_qconv_train_vectors.argtypes = [ctypes.c_int32, vp, i64, i64, i64, ctypes.c_int32, vp, vp, vp]
     lib.qiddm_qconv_train_partials.restype = ctypes.c_int64
-    lib.qiddm_qconv_train_partials.argtypes = [i64, i64, i64]
+    lib.qiddm_qconv_train_partials.argtypes = [i64, i64, i64, i64]
     lib.qiddm_qconv_train_backward.restype = ctypes.c_int
     lib.qiddm_qconv_train_backward.argtypes = [ctypes.c_int32, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, vp,
                                                ctypes.c_int32, vp, vp, vp, vp]

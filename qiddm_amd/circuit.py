@@ -691,7 +691,7 @@ class _QConvUnitaryFunction(torch.autograd.Function):
         rt = _unitary_rows(u, n_qubits, f, c_out, co, device)
         xx = _as_f64(x, device).contiguous()
         gy = _as_f64(grad_y, device).contiguous()
-        n_part = lib.qiddm_qconv_train_partials(b, ho, wo)
+        n_part = lib.qiddm_qconv_train_partials(b, ho, wo, f)
         gfeat_t = torch.empty(f, b * ho * wo, dtype=torch.float32, device=device)
         hpart = torch.empty(n_part, 2 * co, f + 1, dtype=torch.float32, device=device)
         gx = torch.empty(b, c, h, w, dtype=torch.float64, device=device) if need_gx else None

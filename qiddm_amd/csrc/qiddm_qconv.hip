@@ -227,10 +227,21 @@ int qiddm_qconv_unitary_forward(int32_t n_qubits, const double* u, const double*
   return QIDDM_OK;
 }
 
-int64_t qiddm_qconv_train_partials(int64_t batch, int64_t height_out, int64_t width_out) {
-  if (batch < 0 || height_out < 1 || width_out < 1) return -1;
-  const int64_t tiles = (batch * height_out * width_out + qiddm::kTcTile - 1) / qiddm::kTcTile;
+namespace {
+int64_t train_grid(int64_t pixels_total) {
+  const int64_t tiles = (pixels_total + qiddm::kTcTile - 1) / qiddm::kTcTile;
   return tiles < 1 ? 1 : (tiles < 512 ? tiles : 512);
+}
+// thread groups of the h product (each: all columns, a share of the tile's pixels)
+int train_groups(int64_t features) {
+  const int64_t g = qiddm::kTcThreads / (features + 1);
+  return g < 1 ? 1 : (g > 8 ? 8 : (int)g);
+}
+}  // namespace
+
+int64_t qiddm_qconv_train_partials(int64_t batch, int64_t height_out, int64_t width_out, int64_t features) {
+  if (batch < 0 || height_out < 1 || width_out < 1 || features < 1) return -1;
+  return train_grid(batch * height_out * width_out);
 }
 
 int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch, int64_t in_channels, int64_t height,
@@ -269,7 +280,8 @@ int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch,
   tc.M = batch * ho * wo;
   tc.pad_norm2 = 0.25f * (float)(d - f);
   tc.post_scale = 0.5f * (float)d;
-  const unsigned grid = (unsigned)qiddm_qconv_train_partials(batch, ho, wo);
+  tc.groups = train_groups(f);
+  const unsigned grid = (unsigned)train_grid(batch * ho * wo);
   hipStream_t st = static_cast<hipStream_t>(stream);
   size_t smem = 0;
   const void* kern = nullptr;

@@ -26,7 +26,8 @@
 namespace qiddm {
 
 struct TrainConv {
-  int32_t C, H, W, kh, kw, ph, pw, Ho, Wo, C_out, F, pad_;
+  int32_t C, H, W, kh, kw, ph, pw, Ho, Wo, C_out, F;
+  int32_t groups;     // thread groups of the h product: each owns all F + 1 columns and 64 / groups pixels of a tile
   int64_t M;          // batch * Ho * Wo
   float pad_norm2;    // 0.25 * (D - F)
   float post_scale;   // D / 2
@@ -74,6 +75,9 @@ __global__ __launch_bounds__(kTcThreads, 1) void qconv_train_backward_kernel(con
   for (int jc = 0; jc < JCH; ++jc)
 #pragma unroll
     for (int cc = 0; cc < K2; ++cc) acc[jc][cc] = 0.f;
+  // the h product: group hg of F + 1 consecutive threads owns pixels [hp_lo, hp_hi) of every tile, thread hj its column
+  const int hg = tid / (F + 1), hj = tid - hg * (F + 1);
+  const int hp_lo = kTcTile * hg / tc.groups, hp_hi = kTcTile * (hg + 1) / tc.groups;
   // this wave's share of the feature columns
   const int jq = (F + NW - 1) / NW;
   const int j_lo = q * jq < F ? q * jq : F, j_hi = (j_lo + jq < F) ? j_lo + jq : F;
@@ -167,27 +171,33 @@ __global__ __launch_bounds__(kTcThreads, 1) void qconv_train_backward_kernel(con
       if (q == NW - 1) s_v[lane * FS + F] = 0.5f * inv;  // the value every pad column holds
     }
     __syncthreads();
-    // ---- h += W2^T v^ over the tile: thread = feature column -------------------------------------------------------------
+    // ---- h += W2^T v^ over the tile: thread = (pixel group, feature column) ------------------------------------------
+    if (hg < tc.groups) {
+      for (int p = hp_lo; p < hp_hi; ++p) {
+        const float v = s_v[p * FS + hj];
+        const float* __restrict__ w = s_w + p * WS;
 #pragma unroll
-    for (int jc = 0; jc < JCH; ++jc) {
-      const int j = tid + jc * kTcThreads;
-      if (j <= F) {
-        for (int p = 0; p < kTcTile; ++p) {
-          const float v = s_v[p * FS + j];
-          const float* __restrict__ w = s_w + p * WS;
-#pragma unroll
-          for (int cc = 0; cc < K2; ++cc) acc[jc][cc] = fmaf(w[cc], v, acc[jc][cc]);
-        }
+        for (int cc = 0; cc < K2; ++cc) acc[0][cc] = fmaf(w[cc], v, acc[0][cc]);
       }
     }
   }
+  // the groups' sums meet in LDS (eight rows at a time through the v^ tile's space): one slab per workgroup
   float* __restrict__ hp = hpart + (size_t)blockIdx.x * K2 * (F + 1);
 #pragma unroll
-  for (int jc = 0; jc < JCH; ++jc) {
-    const int j = tid + jc * kTcThreads;
-    if (j <= F) {
+  for (int c0 = 0; c0 < K2; c0 += 8) {
+    __syncthreads();
+    if (hg < tc.groups) {
 #pragma unroll
-      for (int cc = 0; cc < K2; ++cc) hp[(size_t)cc * (F + 1) + j] = acc[jc][cc];
+      for (int i = 0; i < 8; ++i) s_v[((size_t)hg * 8 + i) * (F + 1) + hj] = acc[0][c0 + i];
+    }
+    __syncthreads();
+    if (hg == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float t = 0.f;
+        for (int g = 0; g < tc.groups; ++g) t += s_v[((size_t)g * 8 + i) * (F + 1) + hj];
+        hp[(size_t)(c0 + i) * (F + 1) + hj] = t;
+      }
     }
   }
 }
