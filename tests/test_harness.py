@@ -82,3 +82,21 @@ def test_graph_mode_reproduces_the_eager_run(tmp_path):
     for (k, a), (_, b) in zip(d1.state_dict().items(), d2.state_dict().items()):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-8), k
     assert torch.allclose(g1, g2, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_unet_simple_trains_through_the_harness_eager_and_recorded(tmp_path):
+    """`UNetUndirectedS` by the drivers' model string (eval(f"nn.{name}")(*params), src/mnist_exm.py:424) on 8 x 8
+    MNIST: the eager loop and the --graph loop (recorded step, fused Adam; QConv2d training through the circuit
+    unitary, HIP BatchNorm) give the same loss curve and weights, and the checkpoint carries the reference's name."""
+    common = ["--model", "UNetUndirectedS", "2", "4", "2", "--data", "mnist_8x8", "--img_size", "8", "--batch_size", "8",
+              "--epochs", "2", "--ds-size", "48", "--label", "0", "--tau", "4", "--device", "cuda"]
+    d1, l1, g1, _ = harness.main(common + ["--save-path", str(tmp_path / "eager")])
+    d2, l2, g2, _ = harness.main(common + ["--save-path", str(tmp_path / "graph"), "--graph"])
+    assert len(l1) == 2 and all(torch.isfinite(torch.tensor(l1)))
+    assert l2 == pytest.approx(l1, rel=1e-4)
+    for (k, a), (_, b) in zip(d1.state_dict().items(), d2.state_dict().items()):
+        assert torch.allclose(a.double(), b.double(), rtol=1e-3, atol=1e-5), k
+    assert any(p.name.startswith("unet_s_undirected_d2_s4_d2") for p in (tmp_path / "eager").parent.iterdir()) or \
+        any("unet_s_undirected_d2_s4_d2" in p.name for p in tmp_path.rglob("*.pt"))
+    assert g1.shape == g2.shape and torch.isfinite(g1).all()
