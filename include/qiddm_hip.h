@@ -378,6 +378,17 @@ int qiddm_batchnorm_backward(const double *x, const double *grad_y, int64_t batc
                              double *grad_x, double *grad_weight, double *grad_bias, void *workspace,
                              int64_t workspace_bytes, void *stream);
 
+/* ---- bilinear x2, float64 (planes, H, W) -> (planes, 2H, 2W) -------------------------------------------
+ * torch.nn.Upsample(scale_factor=2, mode="bilinear") in front of every `up_conv` (reference
+ * nn/unet_simple.py:40-49) and its backward, for training (the eval route reads the x2 inside the GEMM).
+ * ah (2H, H), aw (2W, W): the dense 1-D interpolation matrices (the caller derives them from torch's operator
+ * applied to the identity, so the weights are torch's); forward y = ah x aw^T, backward grad_x = ah^T grad_y aw,
+ * both as gathers over the <= 3 / 4 non-zero entries per row / column.                                      */
+int qiddm_upsample2x_forward(const double *x, int64_t planes, int64_t height, int64_t width, const double *ah,
+                             const double *aw, double *y, void *stream);
+int qiddm_upsample2x_backward(const double *grad_y, int64_t planes, int64_t height, int64_t width,
+                              const double *ah, const double *aw, double *grad_x, void *stream);
+
 /* ---- quantum convolution backward through the circuit unitary (training) ----------------------------------
  * The circuit of QConv2d does not depend on the data (reference nn/qconv.py:51-56), so with U = U(weights):
  * a_mc = sum_j U[2c,j] v^_mj, y_mc = clamp(|a_mc|^2 D/2) for every output pixel m -- and the backward needs no

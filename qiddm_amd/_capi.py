@@ -68,6 +68,8 @@ EXPORTS = (
     "qiddm_batchnorm_workspace_bytes",
     "qiddm_batchnorm_train_forward",
     "qiddm_batchnorm_backward",
+    "qiddm_upsample2x_forward",
+    "qiddm_upsample2x_backward",
     "qiddm_mixed_workspace_bytes",
     "qiddm_mixed_forward",
 )
@@ -150,6 +152,10 @@ def _declare(lib):
     lib.qiddm_qconv_backward.restype = ctypes.c_int
     lib.qiddm_qconv_backward.argtypes = [P, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, vp, i64, vp, vp, vp, vp]
     dbl = ctypes.c_double
+    lib.qiddm_upsample2x_forward.restype = ctypes.c_int
+    lib.qiddm_upsample2x_forward.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp]
+    lib.qiddm_upsample2x_backward.restype = ctypes.c_int
+    lib.qiddm_upsample2x_backward.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp]
     lib.qiddm_qconv_fold_features.restype = ctypes.c_int
     lib.qiddm_qconv_fold_features.argtypes = [vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, vp]
     lib.qiddm_qconv_train_rows.restype = ctypes.c_int

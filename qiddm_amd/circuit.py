@@ -780,6 +780,37 @@ def batch_norm_train(bn: torch.nn.BatchNorm2d, x: torch.Tensor) -> torch.Tensor:
     return _BatchNormTrainFunction.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps)
 
 
+class _Upsample2xFunction(torch.autograd.Function):
+    """Bilinear x2 of a float64 (B, C, H, W) tensor with given 1-D interpolation matrices
+    (``qiddm_upsample2x_forward`` / ``_backward``)."""
+
+    @staticmethod
+    def forward(ctx, x, a_h, a_w):
+        x = x.contiguous()
+        b, c, h, w = x.shape
+        y = torch.empty(b, c, 2 * h, 2 * w, dtype=torch.float64, device=x.device)
+        _capi.check(_capi.lib().qiddm_upsample2x_forward(x.data_ptr(), b * c, h, w, a_h.data_ptr(), a_w.data_ptr(),
+                                                         y.data_ptr(), _stream_ptr(x.device)))
+        ctx.save_for_backward(a_h, a_w)
+        ctx.shape = (b, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        a_h, a_w = ctx.saved_tensors
+        b, c, h, w = ctx.shape
+        gy = gy.contiguous()
+        gx = torch.empty(b, c, h, w, dtype=torch.float64, device=gy.device)
+        _capi.check(_capi.lib().qiddm_upsample2x_backward(gy.data_ptr(), b * c, h, w, a_h.data_ptr(), a_w.data_ptr(),
+                                                          gx.data_ptr(), _stream_ptr(gy.device)))
+        return gx, None, None
+
+
+def upsample2x(x: torch.Tensor, a_h: torch.Tensor, a_w: torch.Tensor) -> torch.Tensor:
+    """``a_h x a_w^T`` per plane for float64 CUDA tensors (a_h: (2H, H), a_w: (2W, W), contiguous float64)."""
+    return _Upsample2xFunction.apply(x, a_h, a_w)
+
+
 def run_shift_sweep(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch.Tensor,
                     precision: str | None = None, with_inputs: bool = True,
                     max_dots_elems: int = 1 << 26):

@@ -173,6 +173,62 @@ __global__ __launch_bounds__(kNormThreads) void bn_back_apply_kernel(const doubl
   }
 }
 
+// ---- bilinear x2 (the `Upsample(scale_factor=2, mode="bilinear")` in front of every `up_conv`, reference
+// nn/unet_simple.py:40-49) with the interpolation weights handed in as the two dense 1-D matrices ah (2H x H) and
+// aw (2W x W) -- the caller takes them from torch's own operator, so the numbers are torch's; row o of such a matrix
+// is non-zero only in columns o/2 - 1 .. o/2 + 1, column i only in rows 2i - 1 .. 2i + 2.
+__global__ __launch_bounds__(256) void upsample2x_forward_kernel(const double* __restrict__ x,
+                                                                 const double* __restrict__ ah,
+                                                                 const double* __restrict__ aw, int64_t planes, int H,
+                                                                 int W, double* __restrict__ y) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Ho = 2 * H, Wo = 2 * W;
+  if (idx >= planes * Ho * Wo) return;
+  const int p = (int)(idx % Wo);
+  const int o = (int)((idx / Wo) % Ho);
+  const int64_t plane = idx / ((int64_t)Wo * Ho);
+  const double* __restrict__ src = x + plane * H * W;
+  double acc = 0;
+  for (int i = o / 2 - 1; i <= o / 2 + 1; ++i) {
+    if (i < 0 || i >= H) continue;
+    const double wh = ah[(size_t)o * H + i];
+    if (wh == 0.0) continue;
+    double row = 0;
+    for (int j = p / 2 - 1; j <= p / 2 + 1; ++j) {
+      if (j < 0 || j >= W) continue;
+      row = fma(aw[(size_t)p * W + j], src[(size_t)i * W + j], row);
+    }
+    acc = fma(wh, row, acc);
+  }
+  y[idx] = acc;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_backward_kernel(const double* __restrict__ gy,
+                                                                  const double* __restrict__ ah,
+                                                                  const double* __restrict__ aw, int64_t planes, int H,
+                                                                  int W, double* __restrict__ gx) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= planes * H * W) return;
+  const int j = (int)(idx % W);
+  const int i = (int)((idx / W) % H);
+  const int64_t plane = idx / ((int64_t)W * H);
+  const int Ho = 2 * H, Wo = 2 * W;
+  const double* __restrict__ src = gy + plane * Ho * Wo;
+  double acc = 0;
+  for (int o = 2 * i - 1; o <= 2 * i + 2; ++o) {
+    if (o < 0 || o >= Ho) continue;
+    const double wh = ah[(size_t)o * H + i];
+    if (wh == 0.0) continue;
+    double row = 0;
+    for (int p = 2 * j - 1; p <= 2 * j + 2; ++p) {
+      if (p < 0 || p >= Wo) continue;
+      row = fma(aw[(size_t)p * W + j], src[(size_t)o * Wo + p], row);
+    }
+    acc = fma(wh, row, acc);
+  }
+  gx[idx] = acc;
+}
+
 }  // namespace qiddm
 
 namespace {
@@ -244,6 +300,30 @@ int qiddm_batchnorm_backward(const double* x, const double* grad_y, int64_t batc
   hipLaunchKernelGGL(qiddm::bn_back_apply_kernel, grid, dim3(qiddm::kNormThreads), 0, st, x, grad_y, g, partial,
                      weight, save_mean, save_invstd, grad_x, grad_weight, grad_bias);
   return launched("bn_back_apply_kernel");
+}
+
+int qiddm_upsample2x_forward(const double* x, int64_t planes, int64_t height, int64_t width, const double* ah,
+                             const double* aw, double* y, void* stream) {
+  if (planes < 1 || height < 1 || width < 1 || height > (1 << 14) || width > (1 << 14))
+    return fail(QIDDM_ERR_INVALID, "bad upsample geometry");
+  if (!x || !ah || !aw || !y) return fail(QIDDM_ERR_INVALID, "x/ah/aw/y is NULL");
+  const int64_t total = planes * 4 * height * width;
+  if (total >= ((int64_t)1 << 39)) return fail(QIDDM_ERR_UNSUPPORTED, "tensor too large for one launch");
+  hipLaunchKernelGGL(qiddm::upsample2x_forward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, ah, aw, planes, (int)height, (int)width, y);
+  return launched("upsample2x_forward_kernel");
+}
+
+int qiddm_upsample2x_backward(const double* grad_y, int64_t planes, int64_t height, int64_t width, const double* ah,
+                              const double* aw, double* grad_x, void* stream) {
+  if (planes < 1 || height < 1 || width < 1 || height > (1 << 14) || width > (1 << 14))
+    return fail(QIDDM_ERR_INVALID, "bad upsample geometry");
+  if (!grad_y || !ah || !aw || !grad_x) return fail(QIDDM_ERR_INVALID, "grad_y/ah/aw/grad_x is NULL");
+  const int64_t total = planes * height * width;
+  if (total >= ((int64_t)1 << 39)) return fail(QIDDM_ERR_UNSUPPORTED, "tensor too large for one launch");
+  hipLaunchKernelGGL(qiddm::upsample2x_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), grad_y, ah, aw, planes, (int)height, (int)width, grad_x);
+  return launched("upsample2x_backward_kernel");
 }
 
 }  // extern "C"

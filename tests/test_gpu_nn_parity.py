@@ -390,3 +390,20 @@ def test_hip_batchnorm_training_matches_torch(shape):
     # eval mode and float32 stay with torch
     mine.eval()
     assert torch.equal(batch_norm_train(mine, x), mine(x))
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 1, 1), (3, 5, 7, 6), (4, 8, 14, 14), (1, 2, 2, 9)])
+def test_hip_bilinear_upsample_matches_torch(shape):
+    """qiddm_upsample2x_forward / _backward vs torch.nn.Upsample(scale_factor=2, mode="bilinear") in float64."""
+    from qiddm_amd.nn.utils import bilinear_upsample2x
+    torch.manual_seed(4)
+    x = torch.randn(*shape, dtype=torch.float64, device="cuda")
+    g = torch.randn(shape[0], shape[1], 2 * shape[2], 2 * shape[3], dtype=torch.float64, device="cuda")
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    ya = torch.nn.Upsample(scale_factor=2, mode="bilinear")(xa)
+    yb = bilinear_upsample2x(xb)
+    (ya * g).sum().backward()
+    (yb * g).sum().backward()
+    assert torch.allclose(ya, yb, rtol=1e-13, atol=1e-13), (ya - yb).abs().max()
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-12, atol=1e-12), (xa.grad - xb.grad).abs().max()
