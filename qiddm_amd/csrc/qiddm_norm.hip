@@ -181,26 +181,34 @@ __global__ __launch_bounds__(256) void upsample2x_forward_kernel(const double* _
                                                                  const double* __restrict__ ah,
                                                                  const double* __restrict__ aw, int64_t planes, int H,
                                                                  int W, double* __restrict__ y) {
+  // one thread per INPUT pixel (i, j): the 2 x 2 output block (2i.., 2j..) from the 3 x 3 patch around it
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int Ho = 2 * H, Wo = 2 * W;
-  if (idx >= planes * Ho * Wo) return;
-  const int p = (int)(idx % Wo);
-  const int o = (int)((idx / Wo) % Ho);
-  const int64_t plane = idx / ((int64_t)Wo * Ho);
+  if (idx >= planes * H * W) return;
+  const int j = (int)(idx % W);
+  const int i = (int)((idx / W) % H);
+  const int64_t plane = idx / ((int64_t)W * H);
   const double* __restrict__ src = x + plane * H * W;
-  double acc = 0;
-  for (int i = o / 2 - 1; i <= o / 2 + 1; ++i) {
-    if (i < 0 || i >= H) continue;
-    const double wh = ah[(size_t)o * H + i];
-    if (wh == 0.0) continue;
-    double row = 0;
-    for (int j = p / 2 - 1; j <= p / 2 + 1; ++j) {
-      if (j < 0 || j >= W) continue;
-      row = fma(aw[(size_t)p * W + j], src[(size_t)i * W + j], row);
-    }
-    acc = fma(wh, row, acc);
-  }
-  y[idx] = acc;
+  const int Wo = 2 * W;
+  // rows 2i (columns i-1, i) and 2i+1 (columns i, i+1) of ah; out-of-range neighbours carry weight 0
+  const int im = i > 0 ? i - 1 : i, ip = i < H - 1 ? i + 1 : i;
+  const int jm = j > 0 ? j - 1 : j, jp = j < W - 1 ? j + 1 : j;
+  const double h0m = i > 0 ? ah[(size_t)(2 * i) * H + im] : 0.0, h0c = ah[(size_t)(2 * i) * H + i];
+  const double h1c = ah[(size_t)(2 * i + 1) * H + i], h1p = i < H - 1 ? ah[(size_t)(2 * i + 1) * H + ip] : 0.0;
+  const double w0m = j > 0 ? aw[(size_t)(2 * j) * W + jm] : 0.0, w0c = aw[(size_t)(2 * j) * W + j];
+  const double w1c = aw[(size_t)(2 * j + 1) * W + j], w1p = j < W - 1 ? aw[(size_t)(2 * j + 1) * W + jp] : 0.0;
+  double r0[3], r1[3], r2[3];  // patch rows i-1, i, i+1 at columns j-1, j, j+1
+  r0[0] = src[(size_t)im * W + jm]; r0[1] = src[(size_t)im * W + j]; r0[2] = src[(size_t)im * W + jp];
+  r1[0] = src[(size_t)i * W + jm];  r1[1] = src[(size_t)i * W + j];  r1[2] = src[(size_t)i * W + jp];
+  r2[0] = src[(size_t)ip * W + jm]; r2[1] = src[(size_t)ip * W + j]; r2[2] = src[(size_t)ip * W + jp];
+  // horizontal pass per patch row: output columns 2j and 2j+1
+  const double a0 = fma(w0m, r0[0], w0c * r0[1]), b0 = fma(w1p, r0[2], w1c * r0[1]);
+  const double a1 = fma(w0m, r1[0], w0c * r1[1]), b1 = fma(w1p, r1[2], w1c * r1[1]);
+  const double a2 = fma(w0m, r2[0], w0c * r2[1]), b2 = fma(w1p, r2[2], w1c * r2[1]);
+  double* __restrict__ dst = y + plane * 4 * H * W + (size_t)(2 * i) * Wo + 2 * j;
+  dst[0] = fma(h0m, a0, h0c * a1);
+  dst[1] = fma(h0m, b0, h0c * b1);
+  dst[Wo] = fma(h1p, a2, h1c * a1);
+  dst[Wo + 1] = fma(h1p, b2, h1c * b1);
 }
 
 __global__ __launch_bounds__(256) void upsample2x_backward_kernel(const double* __restrict__ gy,
@@ -307,8 +315,8 @@ int qiddm_upsample2x_forward(const double* x, int64_t planes, int64_t height, in
   if (planes < 1 || height < 1 || width < 1 || height > (1 << 14) || width > (1 << 14))
     return fail(QIDDM_ERR_INVALID, "bad upsample geometry");
   if (!x || !ah || !aw || !y) return fail(QIDDM_ERR_INVALID, "x/ah/aw/y is NULL");
-  const int64_t total = planes * 4 * height * width;
-  if (total >= ((int64_t)1 << 39)) return fail(QIDDM_ERR_UNSUPPORTED, "tensor too large for one launch");
+  const int64_t total = planes * height * width;
+  if (total >= ((int64_t)1 << 37)) return fail(QIDDM_ERR_UNSUPPORTED, "tensor too large for one launch");
   hipLaunchKernelGGL(qiddm::upsample2x_forward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, ah, aw, planes, (int)height, (int)width, y);
   return launched("upsample2x_forward_kernel");
