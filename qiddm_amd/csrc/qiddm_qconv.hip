@@ -352,8 +352,7 @@ int qiddm_qconv_train_rows(int32_t n_qubits, const double* u, int32_t u_transpos
   if (features < 1 || features > d || out_channels < 1 || 2 * out_channels > d || out_channels > row_channels)
     return fail(QIDDM_ERR_INVALID, "features / out_channels do not fit 2^n or row_channels");
   if (!u || !rows) return fail(QIDDM_ERR_INVALID, "u/rows is NULL");
-  const int64_t total = (features + 1) * row_channels;
-  hipLaunchKernelGGL(qiddm::qconv_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+  hipLaunchKernelGGL(qiddm::qconv_rows_kernel, dim3((unsigned)row_channels), dim3(256), 0,
                      static_cast<hipStream_t>(stream), u, (int)u_transposed, (int)d, (int)features, (int)out_channels,
                      (int)row_channels, rows);
   const hipError_t e = hipGetLastError();
@@ -369,7 +368,7 @@ int qiddm_qconv_train_vectors(int32_t n_qubits, const float* h_partials, int64_t
     return fail(QIDDM_ERR_INVALID, "features / out_channels do not fit 2^n or row_channels");
   if (n_partials < 1 || n_partials > (1 << 20)) return fail(QIDDM_ERR_INVALID, "n_partials out of range");
   if (!h_partials || !psi0 || !lambda) return fail(QIDDM_ERR_INVALID, "h_partials/psi0/lambda is NULL");
-  hipLaunchKernelGGL(qiddm::qconv_vectors_kernel, dim3((unsigned)((features + 1 + 31) / 32), (unsigned)out_channels),
+  hipLaunchKernelGGL(qiddm::qconv_vectors_kernel, dim3((unsigned)((features + 1 + 7) / 8), (unsigned)out_channels),
                      dim3(256), 0,
                      static_cast<hipStream_t>(stream), h_partials, (int)n_partials, (int)d, (int)features,
                      (int)out_channels, (int)row_channels, psi0, lambda);

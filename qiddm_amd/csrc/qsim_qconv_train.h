@@ -206,31 +206,42 @@ __global__ __launch_bounds__(kTcThreads, 1) void qconv_train_backward_kernel(con
 // rt[j][c] = Re U[2c, j], rt[j][CO + c] = Im U[2c, j] for j < F, row F = 0.5 * sum_{j >= F} U[2c, j]
 __global__ __launch_bounds__(256) void qconv_rows_kernel(const double* __restrict__ u, int transposed, int D, int F,
                                                          int C_out, int CO, float* __restrict__ rt) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (j, c) with j <= F
-  if (idx >= (F + 1) * CO) return;
-  const int j = idx / CO, c = idx - j * CO;
+  // one workgroup per channel c (< CO): columns j < F copied, then the pad columns summed by the whole workgroup
+  __shared__ double s_re[4], s_im[4];
+  const int c = blockIdx.x, tid = threadIdx.x;
+  auto elem = [&](int col, double& r, double& i) {
+    const size_t at = transposed ? ((size_t)col * D + 2 * c) : ((size_t)2 * c * D + col);
+    r = u[2 * at];
+    i = u[2 * at + 1];
+  };
+  for (int j = tid; j < F; j += 256) {
+    double re = 0, im = 0;
+    if (c < C_out) elem(j, re, im);
+    rt[(size_t)j * 2 * CO + c] = (float)re;
+    rt[(size_t)j * 2 * CO + CO + c] = (float)im;
+  }
   double re = 0, im = 0;
   if (c < C_out) {
-    auto elem = [&](int col, double& r, double& i) {
-      const size_t at = transposed ? ((size_t)col * D + 2 * c) : ((size_t)2 * c * D + col);
-      r = u[2 * at];
-      i = u[2 * at + 1];
-    };
-    if (j < F) {
-      elem(j, re, im);
-    } else {
-      for (int col = F; col < D; ++col) {
-        double r, i;
-        elem(col, r, i);
-        re += r;
-        im += i;
-      }
-      re *= 0.5;
-      im *= 0.5;
+    for (int col = F + tid; col < D; col += 256) {
+      double r, i;
+      elem(col, r, i);
+      re += r;
+      im += i;
     }
   }
-  rt[(size_t)j * 2 * CO + c] = (float)re;
-  rt[(size_t)j * 2 * CO + CO + c] = (float)im;
+  for (int off = 32; off > 0; off >>= 1) {
+    re += __shfl_down(re, off, 64);
+    im += __shfl_down(im, off, 64);
+  }
+  if ((tid & 63) == 0) {
+    s_re[tid >> 6] = re;
+    s_im[tid >> 6] = im;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    rt[(size_t)F * 2 * CO + c] = (float)(0.5 * (s_re[0] + s_re[1] + s_re[2] + s_re[3]));
+    rt[(size_t)F * 2 * CO + CO + c] = (float)(0.5 * (s_im[0] + s_im[1] + s_im[2] + s_im[3]));
+  }
 }
 
 // h_c from the per-workgroup partial sums, laid out as the start vectors of the matrix-element sweep, and the
@@ -238,14 +249,14 @@ __global__ __launch_bounds__(256) void qconv_rows_kernel(const double* __restric
 __global__ __launch_bounds__(256) void qconv_vectors_kernel(const float* __restrict__ hpart, int n_partials, int D,
                                                             int F, int C_out, int CO, double* __restrict__ psi0,
                                                             double* __restrict__ lambda) {
-  // workgroup = 32 columns x 8 slices of the partial slabs; blockIdx.y = channel
-  __shared__ double s_re[8][33], s_im[8][33];
-  const int jl = threadIdx.x & 31, pg = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + jl, c = blockIdx.y;
+  // workgroup = 8 columns x 32 slices of the partial slabs; blockIdx.y = channel
+  __shared__ double s_re[32][9], s_im[32][9];
+  const int jl = threadIdx.x & 7, pg = threadIdx.x >> 3;
+  const int j = blockIdx.x * 8 + jl, c = blockIdx.y;
   const size_t slab = (size_t)2 * CO * (F + 1);
   double re = 0, im = 0;
   if (j <= F) {
-    for (int p = pg; p < n_partials; p += 8) {
+    for (int p = pg; p < n_partials; p += 32) {
       re += (double)hpart[p * slab + (size_t)c * (F + 1) + j];
       im -= (double)hpart[p * slab + (size_t)(CO + c) * (F + 1) + j];
     }
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(256) void qconv_vectors_kernel(const float* __restr
   s_im[pg][jl] = im;
   __syncthreads();
   if (pg != 0 || j > F) return;
-  for (int g = 1; g < 8; ++g) {
+  for (int g = 1; g < 32; ++g) {
     re += s_re[g][jl];
     im += s_im[g][jl];
   }
