@@ -339,14 +339,19 @@ def test_dense_forward_large_batch_uses_wave_kernel():
     assert torch.allclose(got, ref, atol=1e-4, rtol=1e-4), (got - ref).abs().max()
 
 
-def test_diffusion_sample_uses_fused_steps():
+@pytest.mark.parametrize("ctor,side", [
+    (lambda nn: nn.QIDDM_LL_noise(784, 8, 3, 2), 28),
+    (lambda nn: nn.QIDDM_LL_noise(784, 6, 14, 2), 28),      # the reference's MNIST default, src/mnist_exm.py:46
+    (lambda nn: nn.QNN_noise(64, 4, 2), 8),                  # BASELINE config 1, src/mnist_noise.py:49
+])
+def test_diffusion_sample_uses_fused_steps(ctor, side):
     """Diffusion.sample through the fused sampler == the step-by-step loop == the oracle loop."""
     from qiddm_amd import models, nn, noise
     for goal in ("data", "noise"):
         torch.manual_seed(14)
-        net = nn.QIDDM_LL_noise(784, 8, 3, 2)
-        diff = models.Diffusion(net, noise.add_normal_noise_multiple, goal, (28, 28)).to(DEV, dtype=torch.double).eval()
-        x = (_img(6, 28, 15) * 0.75 + 0.5).to(DEV)
+        net = ctor(nn)
+        diff = models.Diffusion(net, noise.add_normal_noise_multiple, goal, (side, side)).to(DEV, dtype=torch.double).eval()
+        x = (_img(6, side, 15) * 0.75 + 0.5).to(DEV)
         mosaic = diff.sample(first_x=x, n_iters=4)
         with torch.no_grad():
             cur, outs = x, [x]
@@ -354,7 +359,7 @@ def test_diffusion_sample_uses_fused_steps():
                 cur = diff.denoise_step(cur)
                 outs.append(cur)
         st = torch.stack(outs)
-        ref = st[:, :, 0].permute(0, 2, 1, 3).reshape(5 * 28, 6 * 28)
+        ref = st[:, :, 0].permute(0, 2, 1, 3).reshape(5 * side, 6 * side)
         assert mosaic.shape == ref.shape
         assert torch.allclose(mosaic, ref, atol=1e-4), (goal, (mosaic - ref).abs().max())
 
