@@ -1,8 +1,10 @@
 """Oracle restatement of the reference's circuit templates and layer forwards.
 
-TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  **Parity unpinned**
-for the simulator arithmetic (PennyLane absent); the layer glue follows the
-reference lines cited per function.
+TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  The RZ / SEL-CZ /
+<Z> templates are **pinned** to reference-held outputs
+(``tests/test_oracle_reference_runs.py``); the amplitude / SEL-CNOT / probs
+templates are **parity unpinned** (no reference outputs exist for them); the
+layer glue follows the reference lines cited per function.
 
 ``run_circuit`` is the generic executor; the five templates of SURVEY.md
 section 8a are all of the form

@@ -1,9 +1,12 @@
 """Oracle implementation (a): gate-by-gate strided statevector update.
 
-TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  **Parity unpinned**
-(PennyLane is not available offline; conventions below restate its published
-operator definitions, cf. SURVEY.md section 8c "semantics the restatement
-assumes").
+TEST INFRASTRUCTURE ONLY -- see ``oracle/__init__.py``.  Pinning: the RZ /
+Rot / SEL-range / CZ / <Z> / wire-order conventions below are **pinned** to
+PennyLane-Lightning outputs the reference ships
+(``tests/test_oracle_reference_runs.py``); ``amplitude_embedding``,
+``apply_cnot`` and ``probs`` as a returned quantity are **parity unpinned**
+(published definitions + known-answer tests; PennyLane is not available
+offline).
 
 State layout: ``(B, 2**n)`` complex128 torch tensor.  Wire ``w`` is bit
 ``n-1-w`` of the amplitude index (wire 0 = most significant), which is the

@@ -1,0 +1,56 @@
+"""The HIP path against outputs of the REFERENCE ITSELF (PennyLane-Lightning, run by its authors).
+
+``qiddm_amd.nn.QIDDM_PL_noise(784, 8, 6, 2)`` is loaded from each of the five checkpoints the reference ships in
+``results_rebuttal_complex_dataset/*.zip`` and driven through the harness exactly as ``src/bloodmnist.py`` does
+(seed 42 -> ``first_x`` -> ``diff.sample(first_x, n_iters=5)`` -> clamp * 255 -> ``imsave(cmap="gray")``,
+``:231-277, 374-411``); every grey level of the 5 x 10 x 6 shipped PNGs has to come out within 1/255.  This pins
+the C-ABI circuit kernels (RZ re-upload / SEL / CZ ring / <Z>), the seed order of row H and the PCA front-end
+directly against the reference's recorded results -- no oracle in between (the oracle is only used for the PNG
+quantisation model, which is checked against matplotlib itself).
+"""
+import argparse
+import pathlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_runs as rr
+
+RUNS = pathlib.Path(__file__).parent / "golden" / "reference_runs"
+pytestmark = pytest.mark.gpu
+
+
+def _fixtures():
+    d = np.load(RUNS / "steps.npz")
+    return d["steps"].astype(np.int64), [str(n) for n in d["checkpoints"]]
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+@pytest.mark.parametrize("folder", range(5))
+@pytest.mark.parametrize("device_pca", [False, True])
+def test_hip_sampling_reproduces_reference_pngs(folder, precision, device_pca):
+    import qiddm_amd
+    from qiddm_amd import harness, models, nn, noise, pca
+    steps, names = _fixtures()
+    qiddm_amd.set_default_precision(precision)
+    try:
+        # the driver's order: seed -> (data) -> first_x -> constructor draws -> load (src/bloodmnist.py:374-411)
+        torch.manual_seed(42)
+        np.random.seed(42)
+        first_x = torch.rand(10, 1, 28, 28, dtype=torch.double).to("cuda") * 0.75 + 0.5
+        net = harness.build_net(["QIDDM_PL_noise", 784, "8", "6", "2"])
+        net.load_model(RUNS / names[folder])                         # reference nn/qdense.py:1464-1466
+        if device_pca:
+            pca.use_device_pca(net)
+        diff = models.Diffusion(net=net, noise_f=noise.add_normal_noise_multiple, prediction_goal="data",
+                                shape=(28, 28), loss=torch.nn.MSELoss()).to("cuda", dtype=torch.double)
+        args = argparse.Namespace(tau_test=5, img_size=28)
+        gen = harness.test(diff, first_x, args)                      # (6, 10, 1, 28, 28) in [0, 255]
+    finally:
+        qiddm_amd.set_default_precision("f32")
+    assert gen.shape == (6, 10, 1, 28, 28)
+    lv = rr.levels_from_images(gen / 255.0)
+    err = np.abs(lv - steps[folder])
+    assert err.max() <= 1, (folder, precision, err.max())
+    assert (err == 0).mean() > 0.999, (err == 0).mean()
