@@ -138,13 +138,20 @@ def train(diff, loader, args, start_epoch=0, loss_values=None):
     recorded = {}      # the shape of the first batch -> GraphedTrainStep; other shapes (an epoch's last, smaller
                        # batch) run the same fused step eagerly with the same optimizer
     world = dist.get_world_size() if dist.is_initialized() else 1
+    dp_step = parallel.DataParallelStep(diff, opt) if world > 1 else None
     for _ in range(max(args.epochs - start_epoch, 0)):
         epoch_loss = torch.tensor(0.0, dtype=torch.double, device=args.device)
         for (batch,) in loader:
             x = batch.to(args.device, dtype=torch.double)
-            if world > 1:
-                x = parallel.shard_batch(x)
-            if use_graph and world == 1:
+            if dp_step is not None:
+                # every rank sees the global batch (same seeded loader), takes its contiguous shard -- possibly
+                # uneven or empty -- and weights its gradient / loss by local_n / global_n
+                lo, hi = parallel.shard_bounds(x.shape[0], dist.get_rank(), world)
+                out = dp_step(x, T=args.tau, verbose=True)
+                if out is not None:
+                    epoch_loss += out[0].mean() * ((hi - lo) / x.shape[0])
+                continue
+            if use_graph:
                 if not recorded:
                     cpu_rng = torch.get_rng_state()        # recording draws noise too: keep the stream of the run
                     recorded[tuple(x.shape)] = GraphedTrainStep(diff, opt, x, T=args.tau, noise="reference")
@@ -155,9 +162,12 @@ def train(diff, loader, args, start_epoch=0, loss_values=None):
                     continue
             opt.zero_grad()
             batch_loss, _ = diff(x=x, T=args.tau, verbose=True)
-            parallel.all_reduce_gradients(diff.parameters())
             epoch_loss += batch_loss.mean()
             opt.step()
+        if dp_step is not None:
+            red = epoch_loss if dist.get_backend() != "gloo" else epoch_loss.cpu()
+            dist.all_reduce(red, op=dist.ReduceOp.SUM)      # sum of the weighted shard means = the global batch means
+            epoch_loss = red
         loss_values.append(epoch_loss.item())
         print(f"epoch {len(loss_values)}: loss {loss_values[-1]:.6f}", flush=True)
     if args.epochs - start_epoch > 0 and (not dist.is_initialized() or dist.get_rank() == 0):

@@ -114,7 +114,10 @@ class _QuantumNet(nn.Module):
             if prm is None or not prm.requires_grad:
                 continue
             g = g.to(prm.dtype).view_as(prm)
-            prm.grad = g if prm.grad is None else prm.grad + g
+            if prm.grad is None:
+                prm.grad = g
+            else:
+                prm.grad.add_(g)        # in place, as autograd accumulates: .grad may alias a flat DP bucket
         return res
 
 

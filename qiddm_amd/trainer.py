@@ -17,13 +17,19 @@ Adam -- once into HIP graphs and replays them:
   equally distributed stream).
 * ``noise="fused"``: generated inside the fused training step itself (Philox4x32-10 + Box-Muller per element,
   seeded from ``torch.initial_seed()``): no RNG launches at all.  Only for nets with a fused training step.
-* world size > 1: forward+backward and the optimizer are two graphs with the flat-bucket gradient all-reduce
-  (``parallel.all_reduce_gradients``) between them -- the one exchange step of the path (section 8e).
+* world size > 1: every ``.grad`` is a view into one persistent flat buffer (``parallel.GradBucket``) and the
+  gradient all-reduce -- the one exchange step of the path (section 8e) -- is recorded INSIDE the graph between
+  backward and Adam (RCCL collectives are capturable); with a backend that cannot be captured (gloo) the step is
+  two graphs with the eager collective between them.  ``dp_weight`` = local_n / global_n for uneven shards
+  (default 1 / world); ``shard=(global_n, lo, hi)`` makes ``noise="reference"`` draw the single-process field for
+  the global batch and slice it (``parallel.ShardedNoise``).  With ``noise="fused"`` the Philox key mixes the rank in, so shards do not share a field.
 
 Nets with a host-side front-end (the PCA classes, finding F4) cannot be recorded; they raise at capture and
 the caller keeps the eager step.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
@@ -52,7 +58,8 @@ class _StaticNoise:
 
 
 class GraphedTrainStep:
-    def __init__(self, diff, optimizer, x_example, T=10, noise="reference", verbose=False, warmup=3):
+    def __init__(self, diff, optimizer, x_example, T=10, noise="reference", verbose=False, warmup=3,
+                 dp_weight=None, shard=None):
         if noise not in ("reference", "device", "fused"):
             raise ValueError(f"noise must be 'reference', 'device' or 'fused', got {noise!r}")
         if noise == "fused" and getattr(diff.net, "fused_train_step", None) is None:
@@ -63,12 +70,17 @@ class GraphedTrainStep:
             if not group.get("capturable", False):
                 raise ValueError("construct the optimizer with capturable=True")
         self.diff, self.opt, self.T, self.noise_mode, self.verbose = diff, optimizer, T, noise, verbose
+        self.shard = shard          # (global_n, lo, hi): this rank's rows of the global batch, for noise="reference"
+        if shard is not None and dp_weight is None:
+            dp_weight = (shard[2] - shard[1]) / max(shard[0], 1)
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.x = x_example.detach().clone()
         self.noise = torch.empty(self.x.shape, dtype=torch.float32, device=self.x.device)
         self.rng_state = None
         if noise == "fused":
-            self.rng_state = torch.tensor([torch.initial_seed() & ((1 << 63) - 1), 0], dtype=torch.int64, device=self.x.device)
+            rank = dist.get_rank() if dist.is_initialized() else 0
+            seed = (torch.initial_seed() + 0x9E3779B97F4A7C15 * rank) & ((1 << 63) - 1)     # per-rank Philox key
+            self.rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=self.x.device)
             self.noise.fill_(0.5)
         self._draw_noise()
         self._user_noise_f = diff.add_noise
@@ -110,28 +122,53 @@ class GraphedTrainStep:
                         if torch.is_tensor(v):
                             v.zero_()
         # -- record -------------------------------------------------------------------------------------
-        self.opt.zero_grad(set_to_none=True)
         self.g_fwd_bwd = torch.cuda.CUDAGraph()
         self.g_opt = None
-        if self.world == 1:
-            with torch.cuda.graph(self.g_fwd_bwd):
-                self._result = self._fwd_bwd()
-                self.opt.step()
-            if self.rng_state is not None:
-                self.rng_state[1] = 0           # the warm-up and the recording advanced the offset
-        else:
-            with torch.cuda.graph(self.g_fwd_bwd):
-                self._result = self._fwd_bwd()
-            self.g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_opt, pool=self.g_fwd_bwd.pool()):
-                self.opt.step()
-            if self.rng_state is not None:
-                self.rng_state[1] = 0
+        self.bucket = None
         self._params = params
+        if self.world == 1:
+            self.opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(self.g_fwd_bwd):
+                self._result = self._fwd_bwd()
+                self.opt.step()
+        else:
+            # the warm-up left a gradient on every parameter the step trains: move them into ONE persistent flat
+            # buffer (views), so the exchange is a single all-reduce of fixed addresses
+            self.bucket = parallel.GradBucket.for_step(params)
+            self.dp_weight = dp_weight
+            fused = dist.get_backend() == "nccl" and os.environ.get("QIDDM_DP_GRAPH", "fused") != "split"
+            if fused:
+                # RCCL collectives are capturable: zero -> forward+backward -> all-reduce -> Adam is ONE graph
+                try:
+                    with torch.cuda.graph(self.g_fwd_bwd):
+                        self.bucket.zero()
+                        self._result = self._fwd_bwd()
+                        self.bucket.all_reduce(self.dp_weight)
+                        self.opt.step()
+                except Exception as e:     # pragma: no cover - depends on the RCCL build
+                    import warnings
+                    warnings.warn(f"capturing the gradient all-reduce failed ({e!r}); recording two graphs around it")
+                    fused = False
+                    self.g_fwd_bwd = torch.cuda.CUDAGraph()
+            if not fused:
+                with torch.cuda.graph(self.g_fwd_bwd):
+                    self.bucket.zero()
+                    self._result = self._fwd_bwd()
+                self.g_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_opt, pool=self.g_fwd_bwd.pool()):
+                    self.opt.step()
+            self.bucket.check_views()
+        if self.rng_state is not None:
+            self.rng_state[1] = 0               # the warm-up and the recording advanced the offset
 
     def _draw_noise(self):
         if self.noise_mode == "reference":
-            self.noise.copy_(torch.normal(mean=0.5, std=0.2, size=tuple(self.x.shape)), non_blocking=True)
+            if self.shard is None:
+                field = torch.normal(mean=0.5, std=0.2, size=tuple(self.x.shape))
+            else:       # the single-process draw for the global batch, sliced (parallel.ShardedNoise)
+                n, lo, hi = self.shard
+                field = torch.normal(mean=0.5, std=0.2, size=(n,) + tuple(self.x.shape[1:]))[lo:hi]
+            self.noise.copy_(field, non_blocking=True)
 
     def _noise_field(self, data):
         if self.noise_mode == "device":
@@ -154,7 +191,7 @@ class GraphedTrainStep:
         self._draw_noise()
         self.g_fwd_bwd.replay()
         if self.g_opt is not None:
-            parallel.all_reduce_gradients(self._params)
+            self.bucket.all_reduce(self.dp_weight)
             self.g_opt.replay()
         # a replay changes the parameters without any Python-side in-place op: tell torch's version counters, which
         # key the layers' caches of derived data (sampler tables, eval-mode circuit unitaries)
