@@ -143,6 +143,23 @@ def _prep_inputs(circ: Circuit, inputs, dtype, device):
 _workspaces = {}
 
 
+def _scratch(cache: dict, tag, need: int, device, floor: int = 0) -> torch.Tensor:
+    """Launch scratch of >= ``need`` bytes on ``device`` for the current stream.
+
+    Eager launches share one cached buffer per (tag, device, stream), grown on demand (stream order makes the
+    reuse safe).  While the stream is being CAPTURED into a HIP graph the buffer is a fresh allocation from the
+    graph's own memory pool instead -- owned by the recording, never cached, never replaced -- so a later eager call
+    or another recording on a recycled stream handle cannot take a recorded pointer away."""
+    size = max(int(need), int(floor), 1)
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(size, dtype=torch.uint8, device=device)
+    key = (tag, device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = cache.get(key)
+    if buf is None or buf.numel() < size:
+        buf = cache[key] = torch.empty(size, dtype=torch.uint8, device=device)
+    return buf
+
+
 def _workspace(circ: Circuit, precision: str, batch: int, n_replicas: int, device):
     """Per-device scratch for the n > 10 tiled kernel (slabs of concurrently resident workgroups).
     Returns (ptr, nbytes); (0, 0) when the circuit is register-resident."""
@@ -153,11 +170,7 @@ def _workspace(circ: Circuit, precision: str, batch: int, n_replicas: int, devic
         _capi.check(-1)
     if need == 0:
         return 0, 0
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
-    buf = _workspaces.get(key)
-    if buf is None or buf.numel() < need:
-        buf = torch.empty(need, dtype=torch.uint8, device=device)
-        _workspaces[key] = buf
+    buf = _scratch(_workspaces, "tiled", need, device)
     return buf.data_ptr(), need
 
 
@@ -333,10 +346,7 @@ def qconv_unitary_forward(x: torch.Tensor, unitary: torch.Tensor, n_qubits: int,
     need = lib.qiddm_qconv_unitary_workspace_bytes(n_qubits, c, kh, kw, out_channels)
     if need < 0:
         _capi.check(int(need))
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
-    ws = _qconv_workspaces.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _qconv_workspaces[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    ws = _scratch(_qconv_workspaces, "qconv", need, device)
     he, we = (2 * h, 2 * w) if upsample2x else (h, w)
     ho, wo = he + 2 * ph - kh + 1, we + 2 * pw - kw + 1
     y = torch.empty(b, out_channels, max(ho, 0), max(wo, 0), dtype=torch.float64, device=device)
@@ -423,10 +433,7 @@ def train_step(circ: Circuit, x: torch.Tensor, noise: torch.Tensor, schedule: to
     need = lib.qiddm_train_workspace_bytes(ctypes.byref(cs), batch, pixels, tau)
     if need < 0:
         _capi.check(int(need))
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
-    ws = _train_workspaces.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _train_workspaces[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    ws = _scratch(_train_workspaces, "train", need, device)
     f64 = dict(dtype=torch.float64, device=device)
     out = {"loss": torch.empty((), **f64), "w_up": torch.empty_like(wu), "b_up": torch.empty(pixels, **f64)}
     if train_quantum:
@@ -605,10 +612,7 @@ def _angle_grads_from_h(hpart, n_part, angles, n_qubits, f, c_out, co, device):
     kparts = lib.qiddm_matrix_adjoint_partials(c_out)
     kp = torch.empty(kparts, n_rot, 8, dtype=torch.float64, device=device)
     need = lib.qiddm_matrix_adjoint_workspace_bytes(ctypes.byref(cs), c_out)
-    key = ("matrix-adjoint", device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _workspaces[key] = torch.empty(need, dtype=torch.uint8, device=device)
+    ws = _scratch(_workspaces, "matrix-adjoint", need, device)
     _capi.check(lib.qiddm_matrix_adjoint(ctypes.byref(cs), psi0.data_ptr(), lam.data_ptr(), c_out, table.data_ptr(),
                                          kp.data_ptr(), ws.data_ptr(), ws.numel(), st))
     ga = torch.empty(n_rot, 3, dtype=torch.float64, device=device)
@@ -712,11 +716,7 @@ def _norm_workspace(batch, channels, hw, device):
     need = _capi.lib().qiddm_batchnorm_workspace_bytes(batch, channels, hw)
     if need < 0:
         _capi.check(-1)
-    key = ("norm", device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _workspaces[key] = torch.empty(max(need, 1 << 16), dtype=torch.uint8, device=device)
-    return ws
+    return _scratch(_workspaces, "norm", need, device, floor=1 << 16)
 
 
 class _BatchNormTrainFunction(torch.autograd.Function):
@@ -885,10 +885,7 @@ def run_adjoint(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch.Ten
     x_ptr = 0 if x is None else x.data_ptr()
     if circ.n_qubits > 10:
         need = lib.qiddm_adjoint_workspace_bytes(ctypes.byref(cs), batch)
-        key = ("adjoint", device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
-        ws = _workspaces.get(key)
-        if ws is None or ws.numel() < need:
-            ws = _workspaces[key] = torch.empty(need, dtype=torch.uint8, device=device)
+        ws = _scratch(_workspaces, "adjoint", need, device)
         _capi.check(lib.qiddm_backward_adjoint_wide(ctypes.byref(cs), x_ptr, batch, ld, table.data_ptr(),
                                                     g.data_ptr(), g.shape[1], kp.data_ptr(),
                                                     0 if gin is None else gin.data_ptr(), gin_cols, ws.data_ptr(),

@@ -99,13 +99,13 @@ int launch(const Ptrs& ptr, const qiddm::KScalars& p, int64_t n_replicas, hipStr
                 "circuit with %lld Rot gates needs %zu B of LDS for its gate table (limit %zu)",
                 (long long)n_rot, smem, kMaxLds);
   auto kern = qiddm::circuit_kernel<T, N, SHIFT>;
-  static bool big_lds_enabled = false;  // benign race: the attribute call is idempotent
-  if (smem > 48 * 1024 && !big_lds_enabled) {
+  static qiddm_capi::DeviceFlags big_lds_enabled;  // benign race: the attribute call is idempotent
+  if (smem > 48 * 1024 && !big_lds_enabled.get()) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (ea != hipSuccess)
       return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
-    big_lds_enabled = true;
+    big_lds_enabled.set();
   }
   hipLaunchKernelGGL(kern, grid, dim3(waves * qiddm::kWave), smem, stream, static_cast<const T*>(ptr.inputs),
                      static_cast<const T*>(ptr.table), static_cast<T*>(ptr.out),
@@ -139,13 +139,13 @@ int launch_dense_impl(const double* x, const double* wd, const double* bd, const
                       const qiddm::KScalars& p, size_t smem, unsigned blocks, hipStream_t stream) {
   constexpr int waves = WPB;
   auto kern = qiddm::dense_forward_kernel<T, N, LDSW, WPB>;
-  static bool big_lds_enabled = false;
-  if (smem > 48 * 1024 && !big_lds_enabled) {
+  static qiddm_capi::DeviceFlags big_lds_enabled;
+  if (smem > 48 * 1024 && !big_lds_enabled.get()) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (ea != hipSuccess)
       return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
-    big_lds_enabled = true;
+    big_lds_enabled.set();
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(waves * qiddm::kWave), smem, stream, x, wd, bd, angles, wu,
                      bu, y, d, p);
@@ -227,13 +227,13 @@ int launch_qconv(const double* x, const double* angles, double* y, const qiddm::
     return fail(QIDDM_ERR_UNSUPPORTED, "circuit with %lld Rot gates needs %zu B of LDS (limit %zu)",
                 (long long)n_rot, smem, kMaxLds);
   auto kern = qiddm::qconv_forward_kernel<T, N>;
-  static bool big_lds_enabled = false;
-  if (smem > 48 * 1024 && !big_lds_enabled) {
+  static qiddm_capi::DeviceFlags big_lds_enabled;
+  if (smem > 48 * 1024 && !big_lds_enabled.get()) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (ea != hipSuccess)
       return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
-    big_lds_enabled = true;
+    big_lds_enabled.set();
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)bx), dim3(waves * qiddm::kWave), smem, stream, x, angles, y, cv, p);
   const hipError_t e = hipGetLastError();
@@ -299,13 +299,13 @@ int launch_quad(const double* x, const double* wd, const double* bd, const doubl
                 (long long)n_rot, smem, kMaxLds);
   const bool small = d.in_features <= 1024 && d.out_features <= 1024;
   auto kern = small ? qiddm::dense_quad_kernel<T, N, 4> : qiddm::dense_quad_kernel<T, N, 8>;
-  static bool big_lds_enabled[2] = {false, false};
-  if (smem > 48 * 1024 && !big_lds_enabled[small]) {
+  static qiddm_capi::DeviceFlags big_lds_enabled[2];
+  if (smem > 48 * 1024 && !big_lds_enabled[small].get()) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (ea != hipSuccess)
       return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
-    big_lds_enabled[small] = true;
+    big_lds_enabled[small].set();
   }
   const unsigned blocks = (unsigned)(p.batch < 2048 ? p.batch : 2048);
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, stream, x, wd, bd, angles, wu, bu, y,
@@ -401,13 +401,13 @@ int launch_adjoint(const Ptrs& ptr, T* k_partials, T* grad_inputs, const qiddm::
     return fail(QIDDM_ERR_UNSUPPORTED, "circuit with %lld Rot gates needs %zu B of LDS for the adjoint pass",
                 (long long)n_rot, smem);
   auto kern = qiddm::adjoint_kernel<T, N, CONV>;
-  static bool big_lds_enabled = false;
-  if (smem > 48 * 1024 && !big_lds_enabled) {
+  static qiddm_capi::DeviceFlags big_lds_enabled;
+  if (smem > 48 * 1024 && !big_lds_enabled.get()) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (ea != hipSuccess)
       return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
-    big_lds_enabled = true;
+    big_lds_enabled.set();
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)adjoint_blocks<N>(p.batch)), dim3(waves * qiddm::kWave), smem, stream,
                      static_cast<const T*>(ptr.inputs), static_cast<const T*>(ptr.table),
@@ -468,13 +468,13 @@ int launch_tiled(int n, const Ptrs& ptr, const qiddm::KScalars& p, int64_t n_rep
     return fail(QIDDM_ERR_UNSUPPORTED, "circuit with %lld Rot gates needs %zu B of LDS (limit %zu)",
                 (long long)n_rot, smem, kMaxLds);
   auto kern = qiddm::tiled_circuit_kernel<T, SHIFT>;
-  static bool big_lds_enabled = false;
-  if (smem > 48 * 1024 && !big_lds_enabled) {
+  static qiddm_capi::DeviceFlags big_lds_enabled;
+  if (smem > 48 * 1024 && !big_lds_enabled.get()) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (ea != hipSuccess)
       return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
-    big_lds_enabled = true;
+    big_lds_enabled.set();
   }
   dim3 grid((unsigned)tiled_blocks_x(p.batch, SHIFT ? n_replicas : 0), SHIFT ? (unsigned)n_replicas : 1u, 1u);
   qiddm::TiledScalars tp;
@@ -535,12 +535,12 @@ int launch_wide_adjoint(const qiddm_circuit_t* c, const void* inputs, const void
     return fail(QIDDM_ERR_UNSUPPORTED, "circuit with %lld Rot gates needs %zu B of LDS for the adjoint pass",
                 (long long)n_rot, smem);
   auto kern = qiddm::wide_adjoint_kernel<T>;
-  static bool big_lds_enabled = false;
-  if (smem > 48 * 1024 && !big_lds_enabled) {
+  static qiddm_capi::DeviceFlags big_lds_enabled;
+  if (smem > 48 * 1024 && !big_lds_enabled.get()) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (ea != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
-    big_lds_enabled = true;
+    big_lds_enabled.set();
   }
   qiddm::WideAdjointScalars ad;
   ad.gin_ld = gin_ld;

@@ -117,21 +117,21 @@ int qiddm_mixed_forward(int32_t n_qubits, int32_t dtype, const qiddm_mixed_op_t*
   const qiddm::MixedOp* prog = reinterpret_cast<const qiddm::MixedOp*>(ws + g.off_prog);
   if (dtype == QIDDM_F32) {
     auto kern = qiddm::mixed_kernel<float>;
-    static bool big = false;
-    if (smem > 48 * 1024 && !big) {
+    static qiddm_capi::DeviceFlags big;
+    if (smem > 48 * 1024 && !big.get()) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kMaxLds - 4096));  // the kernel also has 2 KiB of static LDS
       if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(e));
-      big = true;
+      big.set();
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)g.blocks), dim3(256), smem, st, prog, angle_rows, features, gates, out,
                        reinterpret_cast<qiddm::V2<float>*>(ws + g.off_slabs), m);
   } else {
     auto kern = qiddm::mixed_kernel<double>;
-    static bool big = false;
-    if (smem > 48 * 1024 && !big) {
+    static qiddm_capi::DeviceFlags big;
+    if (smem > 48 * 1024 && !big.get()) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kMaxLds - 4096));  // the kernel also has 2 KiB of static LDS
       if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(e));
-      big = true;
+      big.set();
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)g.blocks), dim3(256), smem, st, prog, angle_rows, features, gates, out,
                        reinterpret_cast<qiddm::V2<double>*>(ws + g.off_slabs), m);

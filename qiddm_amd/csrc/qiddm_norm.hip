@@ -280,6 +280,9 @@ int qiddm_batchnorm_train_forward(const double* x, int64_t batch, int64_t channe
   if (workspace_bytes < qiddm_batchnorm_workspace_bytes(batch, channels, hw))
     return fail(QIDDM_ERR_INVALID, "workspace too small");
   if (!(eps >= 0.0)) return fail(QIDDM_ERR_INVALID, "eps < 0");
+  if (batch * hw == 1)   // torch.nn.BatchNorm2d in training mode raises for this shape (no variance to estimate)
+    return fail(QIDDM_ERR_INVALID, "Expected more than 1 value per channel when training, got input size (%lld, %lld, %lld)",
+                (long long)batch, (long long)channels, (long long)hw);
   hipStream_t st = static_cast<hipStream_t>(stream);
   double* partial = static_cast<double*>(workspace);
   const dim3 grid((unsigned)g.channels, (unsigned)g.slices);

@@ -49,12 +49,12 @@ int launch_unitary(const qiddm_circuit_t* c, const double* angles, double* u, hi
   if (smem > kMaxLds)
     return fail(QIDDM_ERR_UNSUPPORTED, "circuit with %lld Rot gates needs %zu B of LDS", (long long)n_rot, smem);
   auto kern = qiddm::unitary_kernel<T, N>;
-  static bool big_lds_enabled = false;
-  if (smem > 48 * 1024 && !big_lds_enabled) {
+  static qiddm_capi::DeviceFlags big_lds_enabled;
+  if (smem > 48 * 1024 && !big_lds_enabled.get()) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (ea != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
-    big_lds_enabled = true;
+    big_lds_enabled.set();
   }
   const int groups = (L::D + L::SPW - 1) / L::SPW;
   const int blocks = (groups + waves - 1) / waves;

@@ -51,13 +51,13 @@ template <typename T, int N, bool QUANTUM, int WPB>
 int launch_rows(const qiddm_train_args_t* a, const Geometry& g, unsigned char* ws, const qiddm::TrainScalars& d,
                 const qiddm::KScalars& p, size_t smem, int64_t blocks, hipStream_t st) {
   auto kern = qiddm::train_rows_kernel<T, N, QUANTUM, WPB>;
-  static bool big_lds_enabled = false;
-  if (smem > 48 * 1024 && !big_lds_enabled) {
+  static qiddm_capi::DeviceFlags big_lds_enabled;
+  if (smem > 48 * 1024 && !big_lds_enabled.get()) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (ea != hipSuccess)
       return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
-    big_lds_enabled = true;
+    big_lds_enabled.set();
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(WPB * qiddm::kWave), smem, st,
                      reinterpret_cast<const double*>(ws + g.off_proj), a->b_down, a->angles,

@@ -98,3 +98,83 @@ def test_dp2_matches_single_process():
     for k, v in net.state_dict().items():
         assert torch.allclose(ret[0][k], v, atol=1e-12), k
     assert torch.equal(ret[0]["frozen"], torch.ones(3, dtype=torch.double))
+
+
+# ---- the flat-bucket path: uneven / empty shards, the real noise schedule ---------------------------------------
+def _dp_worker(rank, world, port, ret, batch_sizes):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from qiddm_amd import models, noise, parallel
+        torch.manual_seed(100)
+        net = TinyNet()
+        parallel.broadcast_parameters(net, src=0)
+        diff = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (8, 8), torch.nn.MSELoss())
+        diff.train()
+        opt = torch.optim.Adam(diff.parameters(), lr=0.05)
+        step = parallel.DataParallelStep(diff, opt)
+        torch.manual_seed(7)                                # every rank: the same global batches and noise stream
+        for n in batch_sizes:
+            x_global = torch.rand(n, 64, dtype=torch.double)
+            step(x_global, T=4)
+        step.bucket.check_views()
+        ret[rank] = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        ret[f"rng{rank}"] = torch.get_rng_state()
+        ret[f"bucket{rank}"] = (step.bucket.numel(), len(step.bucket.flats), net.frozen.grad is None)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("batch_sizes", [(5, 1, 6), (1, 3)])
+def test_dp2_uneven_and_empty_shards_match_single_process(batch_sizes):
+    """5 = 3 + 2 (uneven), 1 = 1 + 0 (a rank with an EMPTY shard joins with zeros), real
+    ``add_normal_noise_multiple`` (global draw, sliced): DP-2 == the single-process run, generators in lock-step."""
+    world = 2
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_dp_worker, args=(world, port, ret, batch_sizes), nprocs=world, join=True)
+    for k in ret[0]:
+        assert torch.equal(ret[0][k], ret[1][k]), k
+    assert torch.equal(ret["rng0"], ret["rng1"])
+    # members: lin.weight, lin.bias (float64) + f32p (float32) -> two flat buffers; `frozen` keeps grad None
+    assert ret["bucket0"] == ret["bucket1"] == (64 * 64 + 64 + 5, 2, True)
+    from qiddm_amd import models, noise
+    torch.manual_seed(100)
+    net = TinyNet()
+    diff = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (8, 8), torch.nn.MSELoss())
+    diff.train()
+    opt = torch.optim.Adam(diff.parameters(), lr=0.05)
+    torch.manual_seed(7)
+    for n in batch_sizes:
+        x_global = torch.rand(n, 64, dtype=torch.double)
+        opt.zero_grad()
+        diff(x=x_global, T=4)
+        opt.step()
+    for k, v in net.state_dict().items():
+        tol = 1e-12 if v.dtype == torch.float64 else 1e-6       # the float32 bucket rounds its weighted sum in float32
+        assert torch.allclose(ret[0][k], v, atol=tol, rtol=1e-10), (k, (ret[0][k] - v).abs().max())
+    assert torch.equal(ret["rng0"], torch.get_rng_state())
+
+
+def test_grad_bucket_views_single_process():
+    from qiddm_amd.parallel import GradBucket
+    net = TinyNet()
+    x = torch.rand(4, 64, dtype=torch.double)
+    net(x).sum().backward()
+    want = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    b = GradBucket.for_step(net.parameters())
+    assert net.frozen.grad is None and b.numel() == 64 * 64 + 64 + 5
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, want[n])
+    b.zero()
+    net(x).sum().backward()                       # autograd accumulates into the views in place
+    b.check_views()
+    for n, p in net.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, want[n])
+    torch.optim.SGD(net.parameters(), lr=0.1).zero_grad(set_to_none=True)
+    with pytest.raises(RuntimeError):
+        b.check_views()
