@@ -4,17 +4,18 @@
     python bench.py --gpus N --steps K --warmup W
 
 Metric (BASELINE.json): "denoise-step images/sec + gate-apps/sec, 8-qubit MNIST-28".
-Workload at every N (weak scaling, one process per GPU, no data-path collective --
+Workload at every N (weak scaling, one process per GPU, no data-path collective in the denoise step --
 samples are independent): BASELINE configs[1] = MNIST 28x28, 8-qubit
 qdense ``QNN_noise(784, 8, 14)`` (reference default model, src/mnist_exm.py:48), batch 256 per
 GPU.  One step = one body of ``Diffusion.sample`` (reference src/models.py:127-134):
 ``x <- net(x)`` on a resident (256, 1, 28, 28) float64 batch, i.e.
-linear_down -> [RZ encoders + 14 x (8 Rot + 8 CZ) + <Z>] -> linear_up; `--steps-per-graph` (15 = the
-reference's n_iters per Diffusion.sample call, src/mnist_exm.py:211) consecutive steps of the sampling loop run in ONE launch of the fused sampler (qiddm_dense_sample:
-four wavefronts per sample, the image stays in registers between steps and every intermediate image
-is written out, as Diffusion.sample records it).  Synthetic
-random-noise images (``rand*0.75+0.5``, src/mnist_exm.py:396), random-init weights under
-``torch.manual_seed(42)``.  The step is captured once into a hipGraph and replayed.
+linear_down -> [RZ encoders + 14 x (8 Rot + 8 CZ) + <Z>] -> linear_up.  Consecutive steps of the sampling loop run
+inside ONE launch of the fused sampler (qiddm_dense_sample: four wavefronts per sample, the image stays in
+registers between steps and every intermediate image is written out, as Diffusion.sample records it):
+15 per launch (the reference's n_iters per Diffusion.sample call, src/mnist_exm.py:211), a remainder of K rides in
+the last launch.  Synthetic random-noise images (``rand*0.75+0.5``, src/mnist_exm.py:396), random-init weights
+under ``torch.manual_seed(42)``.  The K steps are recorded into hipGraphs and replayed; the timed region repeats
+the K steps until it is >= 50 ms long (``repeats``), bracketed by barrier + synchronize, max over ranks.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 """
@@ -22,6 +23,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -33,8 +35,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_TF = 157.3           # f32 vector peak (= the f32 MFMA peak), same guide
 BATCH_PER_GPU = 256
 N_QUBITS, QDEPTH, IMG = 8, 14, 28
+MIN_TIMED_S = 0.05
 
 
 def parse():
@@ -49,7 +53,8 @@ def parse():
                          "(15 = the reference's n_iters per Diffusion.sample call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary (non-headline) timings")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget")
+    ap.add_argument("--no-train", action="store_true", help="skip the data-parallel training-step timing")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per variant")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a 1-GPU box: every rank uses cuda:0 and the process "
                          "group is gloo (RCCL refuses two ranks on one device); timings are meaningless")
@@ -78,6 +83,14 @@ def init_dist(args):
     return world, rank, local
 
 
+def _max_over_ranks(v: float, dev) -> float:
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return v
+    t = torch.tensor([v], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
 def build_model(dev):
     from qiddm_amd import models, nn, noise
     torch.manual_seed(42)                                    # --seed default, src/mnist_exm.py:112
@@ -87,60 +100,101 @@ def build_model(dev):
     return diff.eval()
 
 
-def make_runner(diff, x0, use_graph, steps_per_graph, launches_per_graph=5):
-    """Returns run(k): advance the resident batch by exactly k denoise steps.
+def launch_plan(k, spl):
+    """Steps per launch for exactly k consecutive steps: launches of `spl`, the remainder rides in the last one."""
+    if k <= 0:
+        return []
+    full, rest = divmod(k, spl)
+    if full == 0:
+        return [rest]
+    plan = [spl] * full
+    plan[-1] += rest
+    return plan
 
-    The sampling loop of the reference runs n_iters (=15, src/mnist_exm.py:211) dependent steps per call; one
-    launch of the fused sampler holds `steps_per_graph` consecutive steps of that loop.  A recorded graph chains
-    `launches_per_graph` such launches (each reads the previous launch's last image in place) and then refreshes
-    the static input once; smaller graphs (one launch, one step) serve the remainder."""
-    x = x0.clone()
 
-    def chain(launches, m):
+class Runner:
+    """run(k): advance the resident batch by exactly k denoise steps.
+
+    A recorded graph holds up to `launches_per_graph` launches of the fused sampler (each reads the previous launch's
+    last image in place) and then refreshes the static input once.  Graphs are recorded per distinct launch plan,
+    ahead of the timed region (`prepare`)."""
+
+    def __init__(self, diff, x0, use_graph, spl, launches_per_graph=5):
+        self.diff, self.x, self.use_graph, self.spl, self.lpg = diff, x0.clone(), use_graph, spl, launches_per_graph
+        self.graphs = {}
+        if use_graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self._chain((spl,))
+            torch.cuda.current_stream().wait_stream(side)
+
+    def _chain(self, plan):
         with torch.no_grad():
-            cur = x
-            for _ in range(launches):
-                cur = diff.denoise_steps(cur, m)[-1]   # m loop bodies (one launch when the net fuses them)
-            x.copy_(cur)
+            cur = self.x
+            for m in plan:
+                cur = self.diff.denoise_steps(cur, m)[-1]   # m loop bodies (one launch when the net fuses them)
+            self.x.copy_(cur)
 
-    if not use_graph:
-        def run_eager(k):
+    def _chunks(self, k):
+        plan = launch_plan(k, self.spl)
+        return [tuple(plan[i:i + self.lpg]) for i in range(0, len(plan), self.lpg)]
+
+    def prepare(self, k):
+        if not self.use_graph:
+            return
+        for chunk in set(self._chunks(k)):
+            if chunk not in self.graphs:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._chain(chunk)                      # lazily sized buffers of an unseen launch shape
+                torch.cuda.current_stream().wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._chain(chunk)
+                self.graphs[chunk] = g
+
+    def run(self, k):
+        if not self.use_graph:
             for _ in range(k):
-                chain(1, 1)
-        return run_eager, x
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):
-        for _ in range(3):
-            chain(1, steps_per_graph)
-    torch.cuda.current_stream().wait_stream(side)
-    shapes = {(launches_per_graph, steps_per_graph), (1, steps_per_graph), (1, 1)}
-    graphs = {}
-    for launches, m in sorted(shapes):
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            chain(launches, m)
-        graphs[(launches, m)] = g
+                self._chain((1,))
+            return
+        for chunk in self._chunks(k):
+            self.graphs[chunk].replay()
 
-    def run(k):
-        big, rest = divmod(k, launches_per_graph * steps_per_graph)
-        mid, rest = divmod(rest, steps_per_graph)
-        for _ in range(big):
-            graphs[(launches_per_graph, steps_per_graph)].replay()
-        for _ in range(mid):
-            graphs[(1, steps_per_graph)].replay()
-        for _ in range(rest):
-            graphs[(1, 1)].replay()
-    return run, x
+
+def timed_region(runner, steps, warmup, world, dev):
+    """W untimed steps, then `repeats` x exactly K steps between barrier + synchronize; returns (seconds, repeats)."""
+    runner.prepare(steps)
+    runner.prepare(warmup)
+    runner.run(warmup)
+    torch.cuda.synchronize()
+    # calibrate the repeat count on one untimed pass of the K steps (every rank must use the same count)
+    t0 = time.perf_counter()
+    runner.run(steps)
+    torch.cuda.synchronize()
+    once = _max_over_ranks(time.perf_counter() - t0, dev)
+    repeats = max(1, int(math.ceil(MIN_TIMED_S / max(once, 1e-7))))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        runner.run(steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    return _max_over_ranks(time.perf_counter() - t0, dev), repeats
 
 
 def time_dominant_kernel(diff, x_dev, steps_per_launch, launches=100):
-    """Average duration of the dominant kernel -- the fused sampler `dense_quad_kernel<float, 8, 4>`
+    """Average duration of the dominant kernel -- the fused sampler `dense_quad_kernel<T, 8, 4>`
     running `steps_per_launch` denoise steps per launch, exactly the launch of the timed region --
     measured with HIP events on the stream it is launched on: `launches` back-to-back launches
     inside one hipGraph replay."""
-    circ = diff.net._circuit_descriptor()
-
     def once():
         with torch.no_grad():
             return diff.denoise_steps(x_dev, steps_per_launch)
@@ -165,8 +219,7 @@ def time_dominant_kernel(diff, x_dev, steps_per_launch, launches=100):
         g.replay()
     e1.record()
     torch.cuda.synchronize()
-    avg_us = e0.elapsed_time(e1) * 1e3 / (reps * launches)
-    return avg_us, circ
+    return e0.elapsed_time(e1) * 1e3 / (reps * launches)
 
 
 def _time_fn(fn, iters, warm=3):
@@ -180,6 +233,65 @@ def _time_fn(fn, iters, warm=3):
     return (time.perf_counter() - t0) / iters
 
 
+def _event_time_us(fn, iters, warm=2):
+    """HIP events on torch's current stream -- the stream every qiddm launch of `fn` goes to."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def f64_headline(dev, x0, spl):
+    """The same sampler in the reference's precision (complex128 statevector, finding F5): kernel time per step."""
+    import qiddm_amd
+    qiddm_amd.set_default_precision("f64")
+    try:
+        diff = build_model(dev)
+        us = time_dominant_kernel(diff, x0, spl, launches=20)
+    finally:
+        qiddm_amd.set_default_precision("f32")
+    per_step = us / spl
+    return {"dtype": "f64", "kernel": "qiddm::dense_quad_kernel<double, 8, 4>", "steps_per_launch": spl,
+            "kernel_avg_us": us, "us_per_step": per_step, "images_per_s": x0.shape[0] / (per_step * 1e-6),
+            "gate_apps_per_s": x0.shape[0] * 232 / (per_step * 1e-6),
+            "note": "complex128 statevector + float64 linears: the reference's own precision (src/mnist_exm.py:449)"}
+
+
+def c5_roofline(dev):
+    """BASELINE configs[4]'s per-GPU shard -- the one configuration whose statevector does not fit on chip, so slab
+    sweeps are physical memory traffic: 16-qubit LL-style circuit of ``(2352, 16, 6, 2)`` (two chained rounds of six
+    [RZ(x) ; SEL(2 layers, CZ)] blocks, <Z>), 1024 samples, kernel `wide_cz_kernel` / `tiled_circuit_kernel`.
+    `achieved` = the kernel's own sweep bytes (one read + one write of the 2^n-amplitude slab per pass) / launch
+    time; the in-profile FETCH/WRITE counters (profiles/) say how much of that reaches the memory side."""
+    from qiddm_amd.circuit import Circuit, prepare_gates, run_forward, wide_sweeps_per_sample
+    torch.manual_seed(3)
+    n, batch = 16, 1024
+    circ = Circuit(n_qubits=n, encoding="rz", imprimitive="CZ", measure="expz", n_rounds=2, n_blocks=6, sel_layers=2)
+    w = (torch.randn(circ.angles_shape, dtype=torch.float64) * 0.4).to(dev)
+    x = torch.randn(batch, n, device=dev)
+    table = prepare_gates(circ, w, "f32")
+    us = _event_time_us(lambda: run_forward(circ, x, w, "f32", table=table), iters=5, warm=2)
+    sweeps, kernel = wide_sweeps_per_sample(circ, "f32")
+    sweep_bytes = sweeps * 2 * 8 * (1 << n) * batch                    # read + write of every complex64 amplitude
+    alg = circ.algorithmic_bytes_per_sample("f32") * batch
+    ach = sweep_bytes / (us * 1e-6) / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "traffic": None, "kernel": kernel, "workload": "C5 shard: 16-qubit LL-style (2352,16,6,2) circuit, 1024 samples",
+            "kernel_avg_us": us, "circuits_per_s": batch / (us * 1e-6),
+            "gate_apps_per_s": batch * circ.gate_count() / (us * 1e-6),
+            "sweeps_per_sample": sweeps, "sweep_bytes_per_launch": sweep_bytes,
+            "hbm_equivalent": {"bytes_per_launch": alg, "GBps": alg / (us * 1e-6) / 1e9,
+                               "note": "SURVEY 8d per-gate model (16*2^n B per gate application); exceeds the HBM peak "
+                                       "because one sweep applies a whole layer"},
+            "note": "traffic: see profiles/ (separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_wide.py)"}
+
+
 def secondary_measurements(dev, batch):
     """Other members of the same path on the same (batch, 1, 28, 28) shape -- reported next to the
     headline number, never instead of it: the re-uploading LL-style net, the
@@ -187,30 +299,21 @@ def secondary_measurements(dev, batch):
     from qiddm_amd import models, nn, noise
     out = {}
     x = (torch.rand(batch, 1, IMG, IMG, dtype=torch.double) * 0.75 + 0.5).to(dev)
-    try:
-        torch.manual_seed(42)
-        ll = nn.QIDDM_LL_noise(IMG * IMG, 8, 6, 2).to(dev, dtype=torch.double).eval()
-        # same measurement as the headline: the sampling loop, 10 consecutive steps per recorded launch
-        ll_diff = models.Diffusion(ll, noise.add_normal_noise_multiple, "data", (IMG, IMG)).to(dev, dtype=torch.double).eval()
-        run, _ = make_runner(ll_diff, x, True, 15)
-        run(150)
-        t = _time_fn(lambda: run(75), 20) / 75
-        out["denoise_images_per_s_QIDDM_LL_noise(784,8,6,2)"] = batch / t
-        out["gate_apps_per_s_QIDDM_LL_noise(784,8,6,2)"] = batch * 480 / t
-    except Exception as e:  # pragma: no cover
-        out["ll_error"] = repr(e)
-    try:
-        # the reference's own MNIST default (src/mnist_exm.py:46): 6 qubits, 14 x 2 layers, two rounds (G = 840)
-        torch.manual_seed(42)
-        ll6 = nn.QIDDM_LL_noise(IMG * IMG, 6, 14, 2).to(dev, dtype=torch.double).eval()
-        ll6_diff = models.Diffusion(ll6, noise.add_normal_noise_multiple, "data", (IMG, IMG)).to(dev, dtype=torch.double).eval()
-        run, _ = make_runner(ll6_diff, x, True, 15)
-        run(150)
-        t = _time_fn(lambda: run(75), 20) / 75
-        out["denoise_images_per_s_QIDDM_LL_noise(784,6,14,2)"] = batch / t
-        out["gate_apps_per_s_QIDDM_LL_noise(784,6,14,2)"] = batch * 840 / t
-    except Exception as e:  # pragma: no cover
-        out["ll6_error"] = repr(e)
+    for tag, ctor, gates in (("QIDDM_LL_noise(784,8,6,2)", lambda: nn.QIDDM_LL_noise(IMG * IMG, 8, 6, 2), 480),
+                             # the reference's own MNIST default (src/mnist_exm.py:46): 6 qubits, G = 840
+                             ("QIDDM_LL_noise(784,6,14,2)", lambda: nn.QIDDM_LL_noise(IMG * IMG, 6, 14, 2), 840)):
+        try:
+            torch.manual_seed(42)
+            net = ctor().to(dev, dtype=torch.double).eval()
+            d = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (IMG, IMG)).to(dev, dtype=torch.double).eval()
+            r = Runner(d, x, True, 15)
+            r.prepare(75)
+            r.run(150)
+            t = _time_fn(lambda: r.run(75), 20) / 75
+            out[f"denoise_images_per_s_{tag}"] = batch / t
+            out[f"gate_apps_per_s_{tag}"] = batch * gates / t
+        except Exception as e:  # pragma: no cover
+            out[f"error_{tag}"] = repr(e)
     try:
         torch.manual_seed(42)
         unet = nn.UNetUndirectedS(3, 8, 3).to(dev, dtype=torch.double).eval()
@@ -236,17 +339,19 @@ def secondary_measurements(dev, batch):
         out["unet_error"] = repr(e)
     try:
         # BASELINE config 4's layer: 12-qubit QConv2d(256 -> 256, 3x3, qdepth 3), eval mode = the one GEMM of the path
-        # (implicit-im2col 65536 x 2304 by 2304 x 512 on the f32 MFMA); bound: mfma
+        # (implicit-im2col 65536 x 2304 by 2304 x 512 on the f32 MFMA); bound: mfma.  HIP events on the launch stream
+        # around pack + GEMM; profiles/ holds the rocprofv3 line of qconv_gemm_wide_kernel alone.
         torch.manual_seed(42)
         conv = nn.QConv2d(256, 256, qdepth=3).to(dev).eval()
         xc = torch.rand(64, 256, 32, 32, dtype=torch.double, device=dev)
         with torch.no_grad():
-            t = _time_fn(lambda: conv(xc), 5, warm=1)
+            us = _event_time_us(lambda: conv(xc), 5, warm=2)
         px = xc.shape[0] * 32 * 32
-        tf = 2.0 * 2304 * 512 * px / t / 1e12
-        out["qconv12_eval_pixels_per_s"] = px / t
-        out["qconv12_roofline"] = {"bound": "mfma", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
-                                   "kernel": "qiddm::qconv_gemm_wide_kernel"}
+        tf = 2.0 * 2304 * 512 * px / (us * 1e-6) / 1e12
+        out["qconv12_eval_pixels_per_s"] = px / (us * 1e-6)
+        out["qconv12_roofline"] = {"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TF, "unit": "TFLOP/s",
+                                   "frac": tf / VALU_PEAK_TF, "kernel": "qiddm::qconv_gemm_wide_kernel",
+                                   "layer_us": us, "note": "pack + GEMM launches together (lower bound for the GEMM)"}
         del conv, xc
     except Exception as e:  # pragma: no cover
         out["qconv12_error"] = repr(e)
@@ -306,9 +411,64 @@ def secondary_measurements(dev, batch):
     return out
 
 
+def dp_train_measurement(dev, batch, world, rank):
+    """The data-parallel TRAINING step of the flagship: every rank's shard of `batch` images
+    x tau = 10 noise levels through the fused forward + adjoint backward, ONE flat-bucket gradient all-reduce (RCCL,
+    recorded inside the step's HIP graph), one-launch Adam.  Timed like the headline (barrier, max over ranks).
+    `allreduce_us`: the collective alone on the same bucket, back to back on the stream."""
+    from qiddm_amd import models, nn, noise
+    from qiddm_amd.optim import FusedAdam
+    from qiddm_amd.trainer import GraphedTrainStep
+    out = {}
+    tau = 10
+    torch.manual_seed(42)
+    net = nn.QNN_noise(IMG * IMG, N_QUBITS, QDEPTH, detach_quantum=False)
+    net.qnode.diff_method = "adjoint"
+    diff = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (IMG, IMG),
+                            torch.nn.MSELoss()).to(dev, dtype=torch.double).train()
+    torch.manual_seed(2000 + rank)                       # every rank its own shard (and its own device noise stream)
+    xt = torch.rand(batch, IMG * IMG, dtype=torch.double, device=dev)
+    gstep = GraphedTrainStep(diff, FusedAdam(diff.parameters(), lr=1e-3), xt, T=tau, noise="fused")
+    for _ in range(5):
+        gstep(xt)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    iters = 200
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        gstep(xt)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = _max_over_ranks(time.perf_counter() - t0, dev)
+    out["train_images_per_s"] = world * batch * tau * iters / el
+    out["train_us_per_step"] = el / iters * 1e6
+    out["train_config"] = (f"QNN_noise(784,8,14), every parameter trained (adjoint), {batch} images x tau {tau} per GPU, "
+                           f"dp{world}, step recorded in " + ("one HIP graph incl. the all-reduce" if gstep.g_opt is None
+                                                              else "two HIP graphs around an eager all-reduce"))
+    if world > 1 and gstep.bucket is not None:
+        flat = next(iter(gstep.bucket.flats.values()))
+        probe = torch.zeros_like(flat)
+        for _ in range(10):
+            dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        out["allreduce_us"] = _max_over_ranks(time.perf_counter() - t0, dev) / 200 * 1e6
+        out["allreduce_bytes"] = flat.numel() * flat.element_size()
+    return out
+
+
 def cpu_baseline(diff, x0_cpu, budget_s):
-    """The oracle (CPU restatement of default.qubit's per-gate complex128 update, batched) on the
-    same denoise step, all host threads, bounded sample."""
+    """The oracle (CPU restatement of default.qubit's per-gate complex128 update) on the same denoise step, all
+    host threads, bounded sample.  Two variants: batched (PennyLane parameter broadcasting)
+    and the per-sample loop the reference's QNN_noise.forward actually runs (nn/qdense.py:278-281)."""
     from oracle import circuits as oc
     sd = {k[4:]: v.detach().cpu() for k, v in diff.state_dict().items()}
 
@@ -316,8 +476,18 @@ def cpu_baseline(diff, x0_cpu, budget_s):
         return oc.qnn_forward(t, sd["linear_down.weight"], sd["linear_down.bias"], sd["weights"],
                               sd["linear_up.weight"], sd["linear_up.bias"])
 
-    x = x0_cpu
+    def net_per_sample(t):
+        # linear_down on the batch, then one circuit evaluation per sample in a Python loop, stacked, linear_up
+        b = t.shape[0]
+        xr = t.reshape(b, -1) @ sd["linear_down.weight"].T + sd["linear_down.bias"]
+        spec = oc.Spec(n=N_QUBITS, encoding="rz", imprimitive="CZ", measure="expz")
+        w = sd["weights"].unsqueeze(0)
+        ev = torch.stack([oc.run_round(spec, xr[i], w)[0] for i in range(b)])
+        return (ev @ sd["linear_up.weight"].T + sd["linear_up.bias"]).reshape(t.shape)
+
+    res = {}
     with torch.no_grad():
+        x = x0_cpu
         net(x)                                   # warm-up
         n, t0 = 0, time.perf_counter()
         while True:
@@ -326,22 +496,19 @@ def cpu_baseline(diff, x0_cpu, budget_s):
             el = time.perf_counter() - t0
             if el > budget_s or n >= 1000:
                 break
-    return n * x.shape[0] / el, n, el
-
-
-def load_pmc_traffic(kernel_substr, batch):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_traffic.py)."""
-    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if not os.path.exists(path):
-        return None
-    try:
-        rec = json.load(open(path))
-        for r in rec.get("kernels", []):
-            if kernel_substr in r["kernel"] and r.get("batch") == batch:
-                return r["hbm_bytes_per_launch"]
-    except Exception:
-        return None
-    return None
+        res["batched"] = (n * x.shape[0] / el, f"{n} denoise steps of the same batch-{x.shape[0]} workload in {el:.1f} s")
+        xs = x0_cpu[:16]
+        net_per_sample(xs[:2])
+        n, t0 = 0, time.perf_counter()
+        while True:
+            net_per_sample(xs)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 1000:
+                break
+        res["per_sample_loop"] = (n * xs.shape[0] / el, f"{n} denoise steps of 16 images of the same workload, one "
+                                                        f"circuit call per image, in {el:.1f} s")
+    return res
 
 
 def main():
@@ -354,36 +521,31 @@ def main():
     diff = build_model(dev)
     torch.manual_seed(1000 + rank)
     x0 = (torch.rand(args.batch, 1, IMG, IMG, dtype=torch.double) * 0.75 + 0.5)
-    run, _state = make_runner(diff, x0.to(dev), use_graph=not args.no_graph,
-                              steps_per_graph=args.steps_per_graph)
+    spl = 1 if args.no_graph else args.steps_per_graph
+    runner = Runner(diff, x0.to(dev), use_graph=not args.no_graph, spl=spl)
+    elapsed, repeats = timed_region(runner, args.steps, args.warmup, world, dev)
 
-    run(args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64,
-                         device="cpu" if dist.get_backend() == "gloo" else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
-
-    images = world * args.batch * args.steps
-    value = images / elapsed
-    result = None
+    total_steps = args.steps * repeats
+    value = world * args.batch * total_steps / elapsed
+    train = None
+    if not args.no_train:
+        try:
+            train = dp_train_measurement(dev, args.batch, world, rank)
+        except Exception as e:  # pragma: no cover - must not cost the headline line
+            train = {"train_error": repr(e)}
     if rank == 0:
-        spl = 1 if args.no_graph else args.steps_per_graph
-        kern_us, circ = time_dominant_kernel(diff, x0.to(dev), spl)
+        plan = launch_plan(args.steps, spl)
+        kspl = max(set(plan), key=plan.count) if plan else spl     # the launch shape the timed region is made of
+        kern_us = time_dominant_kernel(diff, x0.to(dev), kspl)
+        circ = diff.net._circuit_descriptor()
         g_per_sample = circ.gate_count()
-        alg_bytes = circ.algorithmic_bytes_per_sample("f32") * args.batch * spl   # per launch
-        achieved = alg_bytes / (kern_us * 1e-6) / 1e9
+        alg_bytes = circ.algorithmic_bytes_per_sample("f32") * args.batch * kspl   # per launch
+        hbm_eq = alg_bytes / (kern_us * 1e-6) / 1e9
+        # what the kernel actually executes (folded tables): per amplitude and layer one complex multiply (6 flop)
+        # + n real RY updates (6 flop each), plus <Z> and the two linears
+        flop = QDEPTH * (1 << N_QUBITS) * (6 + 6 * N_QUBITS) + 2 * N_QUBITS * (1 << N_QUBITS) + 2 * 2 * IMG * IMG * N_QUBITS
+        valu_tf = flop * args.batch * kspl / (kern_us * 1e-6) / 1e12
+        io_bytes = (kspl + 1) * args.batch * IMG * IMG * 8        # first image in + one image out per step (exact)
         result = {
             "metric": "denoise-step images/sec, 8-qubit MNIST-28",
             "value": value,
@@ -391,7 +553,9 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "repeats": repeats,
+            "timed_region_s": elapsed,
+            "ms_per_step": elapsed / total_steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -402,41 +566,61 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": world * args.batch,
                        "n_qubits": N_QUBITS, "gates_per_sample": g_per_sample,
                        "launch": "eager" if args.no_graph else
-                       f"hipGraph replay, {args.steps_per_graph} consecutive steps per launch, 5 launches per graph",
+                       f"hipGraph replay; launches of the fused sampler hold {plan} steps for K={args.steps}; the K steps "
+                       f"are repeated {repeats}x inside the timed region",
                        "parallelism": f"shard{world}"},
             "gate_apps_per_s": value * g_per_sample,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": load_pmc_traffic("dense_quad_kernel<float, 8, 4>", args.batch),
-                         "kernel": "qiddm::dense_quad_kernel<float, 8, 4>",
-                         "steps_per_launch": spl,
-                         "kernel_avg_us": kern_us,
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         # what the kernel actually executes (folded tables): per amplitude and layer one complex
-                         # multiply (6 flop) + n real RY updates (6 flop each), plus <Z> and the two linears
-                         "valu": (lambda fl: {"executed_flop_per_sample_step": fl,
-                                              "achieved": fl * args.batch * spl / (kern_us * 1e-6) / 1e12,
-                                              "peak": 157.3, "unit": "TFLOP/s",
-                                              "frac": fl * args.batch * spl / (kern_us * 1e-6) / 1e12 / 157.3,
-                                              "note": "latency-bound at batch 256: one sample per CU, one wavefront "
-                                                      "per SIMD, every layer a dependent chain"})(
-                             QDEPTH * (1 << N_QUBITS) * (6 + 6 * N_QUBITS) + 2 * N_QUBITS * (1 << N_QUBITS)
-                             + 2 * 2 * IMG * IMG * N_QUBITS),
-                         "note": "algorithmic = (G+1/2)*16*2^n B per sample (SURVEY 8d) x batch x steps per "
-                                 "launch; the slab lives in registers (4 wavefronts per sample), so physical "
-                                 "HBM traffic is the first image in + one image out per step; the kernel also "
-                                 "does linear_down/linear_up of every step"},
+            "roofline": {
+                # The statevector of an 8-qubit sample (2 KiB) lives in the registers of four wavefronts: the kernel
+                # is bounded by instruction issue / latency on the vector ALU, not by HBM.  frac = executed VALU flop
+                # / f32 vector peak; the counters behind "latency-bound" are in profiles/ (SQ_* passes).
+                "bound": "valu", "achieved": valu_tf, "peak": VALU_PEAK_TF, "unit": "TFLOP/s",
+                "frac": valu_tf / VALU_PEAK_TF,
+                "traffic": None,
+                "kernel": "qiddm::dense_quad_kernel<float, 8, 4>",
+                "steps_per_launch": kspl,
+                "kernel_avg_us": kern_us,
+                "kernel_us_per_step": kern_us / kspl,
+                "executed_flop_per_sample_step": flop,
+                "hbm_physical": {"io_bytes_per_launch": io_bytes, "GBps": io_bytes / (kern_us * 1e-6) / 1e9,
+                                 "frac_of_peak": io_bytes / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                 "note": "images in/out only (exact count); weights and tables come from L2. The measured "
+                                         "2*FETCH_SIZE+WRITE_SIZE per launch is in profiles/ (separate --pmc passes)"},
+                "hbm_equivalent": {"bytes_per_launch": alg_bytes, "GBps": hbm_eq, "x_peak": hbm_eq / HBM_PEAK_GBS,
+                                   "note": "SURVEY 8d accounting, (G+1/2)*16*2^n B per sample: what a one-sweep-per-gate "
+                                           "HBM simulator would move. Not a roofline fraction: the slab never leaves "
+                                           "the registers"},
+                "note": "latency-bound at batch 256: one sample per CU, one wavefront per SIMD, every layer a dependent "
+                        "chain of cross-lane moves",
+            },
         }
+        if train:
+            result.update(train)
+        if world == 1:
+            try:
+                result["f64"] = f64_headline(dev, x0.to(dev), kspl)
+            except Exception as e:  # pragma: no cover
+                result["f64"] = {"error": repr(e)}
+            try:
+                result["roofline_c5"] = c5_roofline(dev)
+            except Exception as e:  # pragma: no cover
+                result["roofline_c5"] = {"error": repr(e)}
         if not args.no_secondary and world == 1:
             result["secondary"] = secondary_measurements(dev, args.batch)
         if not args.no_cpu_baseline and world == 1:
-            v, n_steps, el = cpu_baseline(diff, x0, args.cpu_seconds)
+            cb = cpu_baseline(diff, x0, args.cpu_seconds)
+            v, sample = cb["batched"]
+            vl, sample_l = cb["per_sample_loop"]
             result["cpu_baseline"] = {
                 "value": v, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": f"{n_steps} denoise steps of the same batch-{args.batch} workload in {el:.1f} s "
-                          "(oracle: batched complex128 per-gate torch update)",
-                "gate_apps_per_s": v * g_per_sample}
+                "sample": sample + " (oracle: batched complex128 per-gate torch update)",
+                "gate_apps_per_s": v * g_per_sample,
+                "dtype": "f64",
+                "per_sample_loop": {"value": vl, "unit": "images/s", "sample": sample_l +
+                                    " (the reference's own QNN_noise.forward shape, nn/qdense.py:278-281)"}}
             result["speedup_vs_cpu"] = value / v
+            if "f64" in result and "images_per_s" in result["f64"]:
+                result["speedup_vs_cpu_same_precision"] = result["f64"]["images_per_s"] / v
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -106,6 +106,23 @@ class Circuit:
         return (self.gate_count() + 0.5) * 2 * self.dim * csize
 
 
+def wide_sweeps_per_sample(circ: "Circuit", precision: str = "f32"):
+    """(slab sweeps per sample, kernel name) of the n = 11..16 forward: one sweep = one read + one write of all 2^n
+    amplitudes.  Mirrors the pass program the kernel builds (``qsim_tiled.h: ProgramBuilder``): every layer of
+    single-qubit gates costs one switch of the local-bit set, a CNOT ring closes one more pass; the first pass of a
+    round only writes and the last one only reads, i.e. P passes = P - 1 sweeps."""
+    if circ.n_qubits <= 10:
+        return 0, "qiddm::circuit_kernel"
+    layers = circ.n_blocks * circ.sel_layers
+    passes = 1 + layers
+    if circ.imprimitive == "CNOT":
+        passes += layers
+    if circ.encoding in ("ry", "ry_blocks"):
+        passes += 1 if circ.encoding == "ry" else circ.n_blocks
+    t = "float" if precision == "f32" else "double"
+    return circ.n_rounds * (passes - 1), f"qiddm::tiled_circuit_kernel<{t}, false>"
+
+
 def _stream_ptr(device) -> int:
     return int(torch.cuda.current_stream(device).cuda_stream)
 

@@ -136,3 +136,55 @@ def test_qconv_training_routes_agree_at_full_resolution(c_in, c_out, k, pad):
     assert (gw32 - gw64).abs().max().item() < 1e-3 * max(gw64.abs().max().item(), 1.0)
     assert (gx32 - gx64).abs().max().item() < 1e-3 * max(gx64.abs().max().item(), 1.0)
     assert 0.0 <= y32.min().item() and y32.max().item() <= 1.0
+
+
+def test_c3_unet_simple_at_batch_1024():
+    """C3's net at its full batch: ``UNetUndirectedS(3, 8, 3)`` on (1024, 1, 28, 28) through the eval-mode route
+    (circuit unitaries + MFMA GEMMs).  The oracle takes ~0.6 s per image, so: 8 images of the batch against the
+    oracle, and batch-composition independence (eval mode has no cross-sample term) for all 1024."""
+    from oracle import unet as ou
+    from qiddm_amd import nn
+    torch.manual_seed(31)
+    net = nn.UNetUndirectedS(3, 8, 3).to(DEV, dtype=torch.double).eval()
+    x = torch.rand(1024, 1, 28, 28, dtype=torch.double, device=DEV) * 0.75 + 0.5
+    with torch.no_grad():
+        y = net(x)
+        assert y.shape == (1024, 1, 28, 28) and torch.isfinite(y).all()
+        parts = torch.cat([net(x[i:i + 256]) for i in range(0, 1024, 256)])
+        assert torch.allclose(y, parts, atol=1e-9), (y - parts).abs().max()
+        perm = torch.randperm(1024, device=DEV)
+        assert torch.allclose(net(x[perm]), y[perm], atol=1e-9)
+    idx = torch.tensor([0, 1, 255, 256, 511, 700, 1022, 1023])
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    want = ou.unet_simple_forward(x[idx.to(DEV)].cpu(), sd, 3, 8, training=False)
+    assert torch.allclose(y[idx.to(DEV)].cpu(), want, atol=5e-4, rtol=5e-4), (y[idx.to(DEV)].cpu() - want).abs().max()
+
+
+def test_c4_qconv_layer_at_the_512_image_shard():
+    """C4's layer at the per-GPU shard: 12-qubit ``QConv2d(256, 256, 3x3, qdepth 3)`` on (512, 256, 32, 32) float64
+    (1 GiB in, 1 GiB out; 524 288 circuits) through the eval GEMM route.  Checked against the statevector oracle on
+    48 output pixels spread over the shard (corners, edges, interior), plus range, determinism and chunk equality."""
+    from oracle import circuits as oc
+    from qiddm_amd import nn
+    torch.manual_seed(33)
+    conv = nn.QConv2d(256, 256, qdepth=3).to(DEV).eval()
+    x = torch.rand(512, 256, 32, 32, dtype=torch.double, device=DEV)
+    with torch.no_grad():
+        y = conv(x)
+        assert y.shape == (512, 256, 32, 32)
+        assert 0.0 <= y.min().item() and y.max().item() <= 1.0
+        assert torch.equal(conv(x[100:132]), y[100:132])              # chunk == slice of the shard, bit for bit
+    g = torch.Generator().manual_seed(34)
+    pix = [(0, 0, 0), (511, 31, 31), (17, 0, 31), (300, 31, 0), (256, 15, 16)]
+    pix += [(int(torch.randint(512, (1,), generator=g)), int(torch.randint(32, (1,), generator=g)),
+             int(torch.randint(32, (1,), generator=g))) for _ in range(43)]
+    w = conv.weights.detach().cpu()
+    for b, i, j in pix:
+        # the 3x3 patch around (i, j) with zero padding, as a 1-pixel "image": the oracle's unfold of a 3x3 input
+        # with padding 0 yields exactly that patch
+        patch = torch.zeros(1, 256, 3, 3, dtype=torch.double)
+        i0, i1, j0, j1 = max(i - 1, 0), min(i + 2, 32), max(j - 1, 0), min(j + 2, 32)
+        patch[0, :, i0 - (i - 1):i1 - (i - 1), j0 - (j - 1):j1 - (j - 1)] = x[b, :, i0:i1, j0:j1].cpu()
+        want = oc.qconv2d_forward(patch, w, 256, (3, 3), (0, 0))[0, :, 0, 0]
+        got = y[b, :, i, j].cpu()
+        assert torch.allclose(got, want, atol=2e-4), ((b, i, j), (got - want).abs().max())

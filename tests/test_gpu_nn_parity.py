@@ -345,7 +345,9 @@ def test_dense_forward_large_batch_uses_wave_kernel():
     (lambda nn: nn.QNN_noise(64, 4, 2), 8),                  # BASELINE config 1, src/mnist_noise.py:49
 ])
 def test_diffusion_sample_uses_fused_steps(ctor, side):
-    """Diffusion.sample through the fused sampler == the step-by-step loop == the oracle loop."""
+    """Diffusion.sample through the fused sampler == the package's step-by-step loop == ``oracle.diffusion.sample``
+    around the oracle's float64 restatement of the net."""
+    from oracle import diffusion as odf
     from qiddm_amd import models, nn, noise
     for goal in ("data", "noise"):
         torch.manual_seed(14)
@@ -362,6 +364,18 @@ def test_diffusion_sample_uses_fused_steps(ctor, side):
         ref = st[:, :, 0].permute(0, 2, 1, 3).reshape(5 * side, 6 * side)
         assert mosaic.shape == ref.shape
         assert torch.allclose(mosaic, ref, atol=1e-4), (goal, (mosaic - ref).abs().max())
+        # the oracle loop (reference src/models.py:106-147 around nn/qdense.py:267-289 / :1620-1642)
+        sd = {k[4:]: v.detach().cpu() for k, v in diff.state_dict().items()}
+        if "weights1" in sd:
+            def onet(t):
+                return oc.qiddm_ll_forward(t, sd["linear_down.weight"], sd["linear_down.bias"], sd["weights1"],
+                                           sd["linear_up.weight"], sd["linear_up.bias"])
+        else:
+            def onet(t):
+                return oc.qnn_forward(t, sd["linear_down.weight"], sd["linear_down.bias"], sd["weights"],
+                                      sd["linear_up.weight"], sd["linear_up.bias"])
+        want = odf.sample(onet, x.cpu(), 4, goal)
+        assert torch.allclose(mosaic.cpu(), want, atol=2e-4), (goal, (mosaic.cpu() - want).abs().max())
 
 
 @pytest.mark.parametrize("shape", [(1, 3, 5, 7), (6, 8, 28, 28), (70, 4, 14, 14), (130, 2, 3, 3)])
