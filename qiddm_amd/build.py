@@ -15,7 +15,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libqiddm_hip.so")
-SOURCES = ["qiddm_capi.hip", "qiddm_train.hip", "qiddm_qconv.hip", "qiddm_mixed.hip", "qiddm_norm.hip"]
+SOURCES = ["qiddm_capi.hip", "qiddm_train.hip", "qiddm_qconv.hip", "qiddm_mixed.hip", "qiddm_norm.hip",
+           "qiddm_wide.hip"]
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
 

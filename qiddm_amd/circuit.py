@@ -108,18 +108,22 @@ class Circuit:
 
 def wide_sweeps_per_sample(circ: "Circuit", precision: str = "f32"):
     """(slab sweeps per sample, kernel name) of the n = 11..16 forward: one sweep = one read + one write of all 2^n
-    amplitudes.  Mirrors the pass program the kernel builds (``qsim_tiled.h: ProgramBuilder``): every layer of
+    amplitudes.  CZ circuits with no / RZ encoding run on ``wide_cz_kernel``; the others mirror the pass program the
+    generic tiled kernel builds (``qsim_tiled.h: ProgramBuilder``): every layer of
     single-qubit gates costs one switch of the local-bit set, a CNOT ring closes one more pass; the first pass of a
     round only writes and the last one only reads, i.e. P passes = P - 1 sweeps."""
     if circ.n_qubits <= 10:
         return 0, "qiddm::circuit_kernel"
+    t = "float" if precision == "f32" else "double"
     layers = circ.n_blocks * circ.sel_layers
+    if circ.imprimitive == "CZ" and circ.encoding in ("none", "rz"):
+        # qsim_wide_cz.h: a round's first layer is generated in registers, every further layer is one sweep
+        return circ.n_rounds * (layers - 1), f"qiddm::wide_cz_kernel<{t}, {circ.n_qubits}>"
     passes = 1 + layers
     if circ.imprimitive == "CNOT":
         passes += layers
     if circ.encoding in ("ry", "ry_blocks"):
         passes += 1 if circ.encoding == "ry" else circ.n_blocks
-    t = "float" if precision == "f32" else "double"
     return circ.n_rounds * (passes - 1), f"qiddm::tiled_circuit_kernel<{t}, false>"
 
 

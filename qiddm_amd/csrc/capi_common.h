@@ -29,4 +29,18 @@ struct DeviceFlags {
   void set() { const int d = current(); if (d >= 0) done[d] = true; }
 };
 
+// wide CZ forward (qiddm_wide.hip / qsim_wide_cz.h): n = 11..16, CZ entanglers, no or RZ encoding
+inline bool wide_cz_eligible(const qiddm_circuit_t* c) {
+  return c->n_qubits > QIDDM_MAX_QUBITS_FUSED && c->imprimitive == QIDDM_IMP_CZ &&
+         (c->encoding == QIDDM_ENC_NONE || c->encoding == QIDDM_ENC_RZ);
+}
+int64_t wide_cz_grid(int64_t batch, int64_t slabs);
+
+}  // namespace qiddm_capi
+
+namespace qiddm { struct KScalars; }
+namespace qiddm_capi {
+// `tail`: the per-layer tables behind the gate variants of the gate table; `slabs`: 2^n-amplitude slabs in `ws`
+int launch_wide_cz(int dtype, int n, const void* inputs, const void* tail, void* out, void* ws,
+                   const qiddm::KScalars& p, int64_t slabs, void* stream);
 }  // namespace qiddm_capi

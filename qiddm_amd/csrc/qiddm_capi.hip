@@ -590,7 +590,8 @@ int64_t qiddm_gate_count(const qiddm_circuit_t* c) {
 
 // entries (complex numbers) of the folded per-layer tables appended to the gate table (n <= 10 only)
 static int64_t fold_entries(const qiddm_circuit_t* c, int64_t n_rot) {
-  if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED) return 0;
+  if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED)   // wide CZ forward: (cos, sin)(theta/2) and (cos, sin)(alpha/2) per layer and wire
+    return qiddm_capi::wide_cz_eligible(c) ? 2 * n_rot : 0;
   const int n = c->n_qubits, lb = n < 6 ? n : 6;
   return (n_rot / n) * (n + ((int64_t)1 << lb) + ((int64_t)1 << (n - lb)));
 }
@@ -660,6 +661,13 @@ int qiddm_forward(const qiddm_circuit_t* c, const void* inputs, int64_t batch, i
   if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED) {
     rc = check_workspace(c, batch, 0, workspace, workspace_bytes);
     if (rc != QIDDM_OK) return rc;
+    static const bool force_tiled = std::getenv("QIDDM_WIDE_TILED") != nullptr;   // kernel experiments: A/B
+    if (qiddm_capi::wide_cz_eligible(c) && !force_tiled) {
+      const int64_t n_rot = (int64_t)c->n_rounds * c->n_blocks * c->sel_layers * c->n_qubits;
+      const size_t esz = c->dtype == QIDDM_F32 ? 4 : 8;
+      const char* tail = static_cast<const char*>(gate_table) + (size_t)n_rot * qiddm::kVariants * qiddm::kGateReals * esz;
+      return qiddm_capi::launch_wide_cz(c->dtype, c->n_qubits, inputs, tail, out, workspace, p, 2 * tiled_blocks_x(batch, 0), stream);
+    }
     return c->dtype == QIDDM_F32 ? launch_tiled<float, false>(c->n_qubits, ptr, p, 0, workspace, st)
                                  : launch_tiled<double, false>(c->n_qubits, ptr, p, 0, workspace, st);
   }

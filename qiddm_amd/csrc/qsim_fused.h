@@ -274,6 +274,26 @@ __device__ __forceinline__ void folded_entry(const double* __restrict__ angles, 
   dst[1] = (T)sn;
 }
 
+// entries (complex numbers, type T) of the per-layer tables appended to the gate table for n > 10:
+// per layer  [0, n): (cos, sin)(theta_w / 2)     [n, 2n): (cos, sin)(alpha_w / 2),
+// alpha_w = phi^l_w + omega^{l-1}_w inside a round (li > 0), phi^l_w for a round's first layer (never used: it acts
+// on |0..0> and is a global phase).
+template <typename T>
+__device__ __forceinline__ void wide_fold_entry(const double* __restrict__ angles, int n, int layer, int li, int e,
+                                                T* __restrict__ dst) {
+  double c, s;
+  if (e < n) {
+    table_sincos<T>(0.5 * angles[((size_t)layer * n + e) * 3 + 1], &s, &c);
+  } else {
+    const int w = e - n;
+    double al = angles[((size_t)layer * n + w) * 3 + 0];
+    if (li > 0) al += angles[((size_t)(layer - 1) * n + w) * 3 + 2];
+    table_sincos<T>(0.5 * al, &s, &c);
+  }
+  dst[0] = (T)c;
+  dst[1] = (T)s;
+}
+
 // ---------------------------------------------------------------------------
 // the engine: everything a wave needs to push its samples through the circuit
 // ---------------------------------------------------------------------------
@@ -1127,6 +1147,11 @@ __global__ void prepare_gates_kernel(const double* __restrict__ angles, T* __res
     // the folded tables of a register-resident circuit (n <= 10), appended after the gate variants
     const int64_t j = i - n_rot * kVariants;
     if (j >= fold_entries) return;
+    if (n > 10) {  // per-layer tables of the wide CZ kernel (qsim_wide_cz.h): 2n entries per layer
+      const int layer = (int)(j / (2 * n)), e = (int)(j - (int64_t)layer * 2 * n);
+      wide_fold_entry<T>(angles, n, layer, layer % layers_per_round, e, table + n_rot * kVariants * kGateReals + 2 * j);
+      return;
+    }
     const int lb = n < 6 ? n : 6;
     const int e_per_layer = n + (1 << lb) + (1 << (n - lb));
     const int layer = (int)(j / e_per_layer), e = (int)(j - (int64_t)layer * e_per_layer);

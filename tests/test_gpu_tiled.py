@@ -112,3 +112,51 @@ def test_param_shift_wide(enc, imp, meas):
     assert torch.allclose(ga.cpu(), grads[0], atol=1e-9), (ga.cpu() - grads[0]).abs().max()
     if wrt_x:
         assert torch.allclose(gi.cpu(), grads[1][:, :n], atol=1e-9)
+
+
+# ---- the wide CZ forward (qsim_wide_cz.h): pass structure corner cases --------------------------------------------
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("n", [11, 13, 14, 16])
+@pytest.mark.parametrize("L,S", [(1, 1), (1, 2), (3, 1), (1, 3), (2, 2), (5, 1)])
+@pytest.mark.parametrize("meas", ["expz", "probs"])
+def test_wide_cz_layer_counts(n, L, S, meas, precision):
+    """1 layer (the generated product state is measured directly), even / odd layer counts (the last pass runs on
+    either local-bit set), every layer a block start (S = 1: data re-upload in every diagonal)."""
+    if n == 16 and (precision == "f64" or meas == "probs") and L * S > 3:
+        pytest.skip("oracle time")
+    circ, spec, x, w = _mk(n, "rz", "CZ", meas, N=1, L=L, S=S, batch=3, seed=100 * n + 10 * L + S)
+    got = _run(circ, x, w, precision)
+    ref = oc.run_circuit(spec, x, w)
+    tol = F64_TOL if precision == "f64" else F32_TOL
+    assert torch.allclose(got, ref, **tol), (got - ref).abs().max()
+
+
+@pytest.mark.parametrize("n,meas", [(12, "expz"), (14, "probs"), (16, "expz")])
+def test_wide_cz_chained_rounds_and_scaled_encoding(n, meas):
+    """Three chained rounds (x <- out[:, :n]) and RZ(pi/2 * x) encoding (QIDDM_A_differN_basePL, nn/qdense.py:2215)."""
+    import math
+    from qiddm_amd.circuit import Circuit
+    g = torch.Generator().manual_seed(n)
+    w = torch.randn(3, 2, 2, n, 3, generator=g, dtype=torch.float64) * 0.8
+    x = torch.rand(2, n, generator=g, dtype=torch.float64) * 2 - 1
+    circ = Circuit(n_qubits=n, encoding="rz", imprimitive="CZ", measure=meas, n_rounds=3, n_blocks=2, sel_layers=2,
+                   enc_scale=math.pi / 2)
+    spec = oc.Spec(n=n, encoding="rz", imprimitive="CZ", measure=meas, enc_scale=math.pi / 2)
+    for precision, tol in (("f64", F64_TOL), ("f32", dict(atol=5e-5, rtol=2e-4))):
+        got = _run(circ, x, w, precision)
+        ref = oc.run_circuit(spec, x, w)
+        assert torch.allclose(got, ref, **tol), (precision, (got - ref).abs().max())
+
+
+@pytest.mark.parametrize("n,batch", [(12, 1300), (16, 37)])
+def test_wide_cz_slab_reuse_and_ragged_batches(n, batch):
+    """More samples than resident workgroups (slabs are reused sample after sample), a batch that is not a
+    multiple of anything; probability rows sum to one at full size, spot rows against the oracle."""
+    circ, spec, x, w = _mk(n, "rz", "CZ", "probs", N=1, L=2, S=2, batch=batch, seed=n)
+    got = _run(circ, x, w, "f32")
+    assert got.shape == (batch, 2 ** n)
+    assert torch.allclose(got.sum(1), torch.ones(batch, dtype=torch.float64), atol=2e-5)
+    idx = [0, 1, batch // 2, batch - 1]
+    ref = oc.run_circuit(spec, x[idx], w)
+    assert torch.allclose(got[idx], ref, **F32_TOL), (got[idx] - ref).abs().max()
+    assert _run(circ, x[:0], w, "f32").shape == (0, 2 ** n)
