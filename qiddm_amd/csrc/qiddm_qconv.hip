@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "qsim_qconv_train.h"
+#include "qsim_qconv_train_mfma.h"
 #include "qsim_unitary.h"
 
 namespace {
@@ -228,9 +229,13 @@ int qiddm_qconv_unitary_forward(int32_t n_qubits, const double* u, const double*
 }
 
 namespace {
-int64_t train_grid(int64_t pixels_total) {
+// resident workgroups of the thin-product backward (= per-workgroup h slabs).  The kernel's tiles wait on gathered
+// global loads, so it wants every workgroup the LDS admits: up to four per CU for narrow layers (<= 160 patch
+// features: <= 40 KB of tile per workgroup with 8 channels), two otherwise.
+int64_t train_grid(int64_t pixels_total, int64_t features) {
   const int64_t tiles = (pixels_total + qiddm::kTcTile - 1) / qiddm::kTcTile;
-  return tiles < 1 ? 1 : (tiles < 512 ? tiles : 512);
+  const int64_t cap = features <= 40 ? 2048 : (features <= 160 ? 1024 : 512);
+  return tiles < 1 ? 1 : (tiles < cap ? tiles : cap);
 }
 // thread groups of the h product (each: all columns, a share of the tile's pixels)
 int train_groups(int64_t features) {
@@ -241,7 +246,7 @@ int train_groups(int64_t features) {
 
 int64_t qiddm_qconv_train_partials(int64_t batch, int64_t height_out, int64_t width_out, int64_t features) {
   if (batch < 0 || height_out < 1 || width_out < 1 || features < 1) return -1;
-  return train_grid(batch * height_out * width_out);
+  return train_grid(batch * height_out * width_out, features);
 }
 
 int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch, int64_t in_channels, int64_t height,
@@ -281,12 +286,39 @@ int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch,
   tc.pad_norm2 = 0.25f * (float)(d - f);
   tc.post_scale = 0.5f * (float)d;
   tc.groups = train_groups(f);
-  const unsigned grid = (unsigned)train_grid(batch * ho * wo);
+  if (const char* ev = std::getenv("QIDDM_STAMP_PTR")) tc.stamps = reinterpret_cast<unsigned long long*>(std::strtoull(ev, nullptr, 0));
+  const unsigned grid = (unsigned)train_grid(batch * ho * wo, f);
   hipStream_t st = static_cast<hipStream_t>(stream);
   size_t smem = 0;
   const void* kern = nullptr;
+  unsigned threads = qiddm::kTcThreads;
+  // the three products on the f32 matrix cores (qsim_qconv_train_mfma.h) from 32 patch features on and whenever its
+  // LDS tiles fit; the VALU kernel keeps the narrowest layers (9 / 16 features: the whole backward of the layer measured
+  // 0.37 / 0.55 ms against 0.53 / 0.67 on the MFMA kernel at 2560 x 28 x 28 pixels, tools/stamp_qconv_train.py; from 32
+  // features on the MFMA kernel wins by 0.05 - 0.33 ms per layer) and the widest.  QIDDM_QCONV_VALU=1 / QIDDM_QCONV_MFMA=1:
+  // kernel experiments (A/B on the same box)
+  static const bool env_mfma = std::getenv("QIDDM_QCONV_MFMA") != nullptr;
+  static const bool env_valu = std::getenv("QIDDM_QCONV_VALU") != nullptr;
+  const bool force_valu = env_valu || (f < 32 && !env_mfma);
+  const int jbm = (int)((qiddm::tm_fcols((int)f) / 16 + qiddm::kTmWaves - 1) / qiddm::kTmWaves);
+#define QIDDM_TM_CASE(CO, J)                                                                                     \
+  if (!kern && !force_valu && row_channels == CO && jbm <= J && qiddm::tm_lds_bytes<CO>((int)f) <= kMaxLds) {   \
+    smem = qiddm::tm_lds_bytes<CO>((int)f);                                                                      \
+    kern = reinterpret_cast<const void*>(qiddm::qconv_train_backward_mfma_kernel<CO, J>);                        \
+    threads = qiddm::kTmThreads;                                                                                 \
+  }
+  QIDDM_TM_CASE(8, 2)
+  QIDDM_TM_CASE(8, 4)
+  QIDDM_TM_CASE(8, 8)
+  QIDDM_TM_CASE(16, 2)
+  QIDDM_TM_CASE(16, 4)
+  QIDDM_TM_CASE(16, 8)
+  QIDDM_TM_CASE(32, 2)
+  QIDDM_TM_CASE(32, 4)
+  QIDDM_TM_CASE(32, 8)
+#undef QIDDM_TM_CASE
 #define QIDDM_TC_CASE(CO, J)                                                                      \
-  if (row_channels == CO && jch == J) {                                                           \
+  if (!kern && row_channels == CO && jch == J) {                                                           \
     smem = qiddm::tc_lds_bytes<CO>((int)f);                                                       \
     kern = reinterpret_cast<const void*>(qiddm::qconv_train_backward_kernel<CO, J>);              \
   }
@@ -303,7 +335,7 @@ int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch,
     if (ea != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
   }
   void* args[] = {(void*)&x, (void*)&grad_y, (void*)&rows, (void*)&grad_features_t, (void*)&h_partials, (void*)&tc};
-  hipError_t e = hipLaunchKernel(kern, dim3(grid), dim3(qiddm::kTcThreads), args, smem, st);
+  hipError_t e = hipLaunchKernel(kern, dim3(grid), dim3(threads), args, smem, st);
   if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_train_backward_kernel launch failed: %s", hipGetErrorString(e));
   if (grad_x) {
     const int64_t total = batch * in_channels * height * width;

@@ -31,6 +31,7 @@ struct TrainConv {
   int64_t M;          // batch * Ho * Wo
   float pad_norm2;    // 0.25 * (D - F)
   float post_scale;   // D / 2
+  unsigned long long* stamps;  // diagnostics (QIDDM_STAMP_PTR): per-phase s_memtime sums of workgroup 0, else null
 };
 
 constexpr int kTcWaves = 8;                  // wavefronts per workgroup: they split the feature columns of a tile

@@ -99,6 +99,10 @@ def test_qconv_stack_trains_through_the_adjoint():
     (16, 8, 1, 0, (4, 6), 2, "f32", 2e-4),      # 1x1 up_conv, no pad columns to speak of (16 features on 4 wires)
     (32, 16, 3, 1, (5, 5), 2, "f32", 2e-4),     # 288 features: two column chunks per thread
     (3, 2, 3, 0, (9, 40), 1, "f32", 2e-4),      # several pixel tiles, ragged last tile, no padding
+    (16, 32, 3, 1, (7, 7), 3, "f32", 2e-4),     # the third down block of unet_simple: 144 features, 32 channels
+    (8, 12, 3, 1, (6, 6), 2, "f32", 2e-4),      # 12 channels in the 16-channel kernel: zero channel columns
+    (4, 20, 3, 1, (5, 5), 2, "f32", 2e-4),      # 20 channels in the 32-channel kernel, 36 features
+    (28, 8, 3, 1, (4, 4), 2, "f32", 2e-4),      # 252 features on 8 wires: almost no pad columns, 16 column blocks
 ])
 def test_fused_qconv_backward_vs_oracle_autograd(c_in, c_out, k, pad, hw, qdepth, precision, tol):
     """qiddm_qconv_backward (adjoint sweep with the patch and dL/dy read in place, then the fold): d/dweights and
