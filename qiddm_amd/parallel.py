@@ -133,12 +133,13 @@ class GradBucket:
                 raise RuntimeError("a parameter's .grad no longer aliases the flat bucket; use bucket.zero() instead "
                                    "of optimizer.zero_grad() and accumulate into .grad in place")
 
-    def all_reduce(self, weight: float = None) -> int:
+    def all_reduce(self, weight: float = None, force: bool = False) -> int:
         """The one exchange step: ``grad <- sum_ranks weight_r * grad_r`` in place, ONE collective per dtype.
         ``weight`` = local_n / global_n (default 1 / world: equal shards).  Capturable into a HIP graph (fixed
-        addresses, no allocation).  Returns the number of elements reduced."""
+        addresses, no allocation).  Returns the number of elements reduced.  ``force``: issue the collective even in a
+        one-rank group (how the single-GPU box exercises the recorded RCCL call)."""
         world = _world()
-        if world == 1:
+        if world == 1 and not (force and dist.is_initialized()):
             return 0
         w = (1.0 / world) if weight is None else float(weight)
         for flat in self.flats.values():

@@ -59,7 +59,7 @@ class _StaticNoise:
 
 class GraphedTrainStep:
     def __init__(self, diff, optimizer, x_example, T=10, noise="reference", verbose=False, warmup=3,
-                 dp_weight=None, shard=None):
+                 dp_weight=None, shard=None, force_dp=False):
         if noise not in ("reference", "device", "fused"):
             raise ValueError(f"noise must be 'reference', 'device' or 'fused', got {noise!r}")
         if noise == "fused" and getattr(diff.net, "fused_train_step", None) is None:
@@ -126,7 +126,8 @@ class GraphedTrainStep:
         self.g_opt = None
         self.bucket = None
         self._params = params
-        if self.world == 1:
+        self.force_dp = bool(force_dp) and dist.is_initialized()    # one-rank group: still record the data-parallel step
+        if self.world == 1 and not self.force_dp:
             self.opt.zero_grad(set_to_none=True)
             with torch.cuda.graph(self.g_fwd_bwd):
                 self._result = self._fwd_bwd()
@@ -136,6 +137,10 @@ class GraphedTrainStep:
             # buffer (views), so the exchange is a single all-reduce of fixed addresses
             self.bucket = parallel.GradBucket.for_step(params)
             self.dp_weight = dp_weight
+            # one eager exchange first: the communicator (RCCL: connections, channels, scratch) must exist before a
+            # collective can be recorded into a graph; the values are discarded (the recorded step zeroes the bucket)
+            self.bucket.all_reduce(self.dp_weight, force=self.force_dp)
+            torch.cuda.synchronize()
             fused = dist.get_backend() == "nccl" and os.environ.get("QIDDM_DP_GRAPH", "fused") != "split"
             if fused:
                 # RCCL collectives are capturable: zero -> forward+backward -> all-reduce -> Adam is ONE graph
@@ -143,7 +148,7 @@ class GraphedTrainStep:
                     with torch.cuda.graph(self.g_fwd_bwd):
                         self.bucket.zero()
                         self._result = self._fwd_bwd()
-                        self.bucket.all_reduce(self.dp_weight)
+                        self.bucket.all_reduce(self.dp_weight, force=self.force_dp)
                         self.opt.step()
                 except Exception as e:     # pragma: no cover - depends on the RCCL build
                     import warnings
@@ -191,7 +196,7 @@ class GraphedTrainStep:
         self._draw_noise()
         self.g_fwd_bwd.replay()
         if self.g_opt is not None:
-            self.bucket.all_reduce(self.dp_weight)
+            self.bucket.all_reduce(self.dp_weight, force=self.force_dp)
             self.g_opt.replay()
         # a replay changes the parameters without any Python-side in-place op: tell torch's version counters, which
         # key the layers' caches of derived data (sampler tables, eval-mode circuit unitaries)

@@ -198,3 +198,45 @@ def test_graphed_step_with_unet_simple_and_batchnorm_buffers():
             assert torch.allclose(a, b, rtol=1e-6, atol=1e-9), k
         else:
             assert torch.equal(a, b), k           # num_batches_tracked
+
+
+def test_recorded_data_parallel_step_with_rccl_in_the_graph():
+    """The data-parallel form of the recorded step on the one GPU of the box: a ONE-rank RCCL ("nccl") group, every
+    ``.grad`` a view into the flat bucket, bucket.zero -> forward+backward -> all_reduce -> Adam recorded as ONE HIP
+    graph (``force_dp``).  With one rank the collective is the identity, so the numbers must equal the eager loop --
+    what is under test is that the RCCL call records and replays, that the fused training step and the one-launch Adam
+    work on bucket views, and that nothing detaches them."""
+    import socket
+    import torch.distributed as dist
+    from qiddm_amd.optim import FusedAdam
+    from qiddm_amd.trainer import GraphedTrainStep
+    xs = [torch.rand(6, 64, dtype=torch.double, device="cuda") for _ in range(3)]
+    eager = _make(False, "adjoint")
+    opt_e = torch.optim.Adam(eager.parameters(), lr=1e-2)
+    torch.manual_seed(123)
+    losses_e = []
+    for x in xs:
+        opt_e.zero_grad()
+        (loss,) = eager(x=x, T=5)
+        opt_e.step()
+        losses_e.append(loss.item())
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        rec = _make(False, "adjoint")
+        torch.manual_seed(99)
+        step = GraphedTrainStep(rec, FusedAdam(rec.parameters(), lr=1e-2), xs[0], T=5, noise="reference", force_dp=True)
+        assert step.bucket is not None and step.g_opt is None          # one graph, the collective inside it
+        assert step.bucket.numel() == sum(p.numel() for p in rec.parameters())
+        torch.manual_seed(123)
+        losses_r = [step(x)[0].item() for x in xs]
+        step.bucket.check_views()
+    finally:
+        dist.destroy_process_group()
+    assert losses_r == pytest.approx(losses_e, rel=1e-9, abs=1e-12)
+    for (k, a), (_, b) in zip(eager.state_dict().items(), rec.state_dict().items()):
+        assert torch.allclose(a, b, rtol=1e-7, atol=1e-10), k
