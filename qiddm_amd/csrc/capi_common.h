@@ -35,6 +35,9 @@ inline bool wide_cz_eligible(const qiddm_circuit_t* c) {
          (c->encoding == QIDDM_ENC_NONE || c->encoding == QIDDM_ENC_RZ);
 }
 int64_t wide_cz_grid(int64_t batch, int64_t slabs);
+// pass-structured reverse sweep (qsim_wide_cz_adjoint.h): one round of >= 2 layers of that family.
+// QIDDM_WIDE_TILED=1 keeps the generic per-gate kernels (kernel experiments: A/B on the same box)
+bool wide_cz_adjoint_eligible(const qiddm_circuit_t* c);
 
 }  // namespace qiddm_capi
 
@@ -43,4 +46,8 @@ namespace qiddm_capi {
 // `tail`: the per-layer tables behind the gate variants of the gate table; `slabs`: 2^n-amplitude slabs in `ws`
 int launch_wide_cz(int dtype, int n, const void* inputs, const void* tail, void* out, void* ws,
                    const qiddm::KScalars& p, int64_t slabs, void* stream);
+// `partials`: `grid` slabs of `slab_stride` elements ([layer][theta | alpha][16]); `ws`: `grid` pairs of slabs
+int launch_wide_cz_adjoint(int dtype, int n, const void* inputs, const void* tail, const void* gout, void* partials,
+                           int64_t slab_stride, void* grad_inputs, int64_t gin_ld, void* ws, const qiddm::KScalars& p,
+                           int64_t grid, void* stream);
 }  // namespace qiddm_capi

@@ -760,6 +760,14 @@ int qiddm_backward_adjoint_wide(const qiddm_circuit_t* c, const void* inputs, in
   p.g_ld = g_ld;
   p.batch = batch;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (batch > 0 && qiddm_capi::wide_cz_adjoint_eligible(c)) {
+    // pass-structured reverse sweep; the slabs then hold per-layer angle-gradient sums (qiddm_adjoint_finalize knows)
+    const int64_t n_rot = (int64_t)c->n_blocks * c->sel_layers * c->n_qubits;
+    const size_t esz = c->dtype == QIDDM_F32 ? 4 : 8;
+    const char* tail = static_cast<const char*>(gate_table) + (size_t)n_rot * qiddm::kVariants * qiddm::kGateReals * esz;
+    return qiddm_capi::launch_wide_cz_adjoint(c->dtype, c->n_qubits, inputs, tail, grad_out, k_partials, n_rot * 8,
+                                              grad_inputs, gin_ld, workspace, p, wide_adjoint_blocks(batch), stream);
+  }
   return c->dtype == QIDDM_F32
              ? launch_wide_adjoint<float>(c, inputs, gate_table, grad_out, k_partials, grad_inputs, workspace, p, gin_ld, st)
              : launch_wide_adjoint<double>(c, inputs, gate_table, grad_out, k_partials, grad_inputs, workspace, p, gin_ld, st);
@@ -918,7 +926,8 @@ int qiddm_adjoint_finalize(const qiddm_circuit_t* c, const double* angles, const
   const int64_t n_rot = (int64_t)c->n_rounds * c->n_blocks * c->sel_layers * c->n_qubits;
   const unsigned blocks = (unsigned)n_rot;  // one wavefront per gate
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (make_params(c).fold && c->n_qubits >= 2 && c->n_qubits <= qiddm::kFoldedAdjointMaxQubits) {
+  if ((make_params(c).fold && c->n_qubits >= 2 && c->n_qubits <= qiddm::kFoldedAdjointMaxQubits) ||
+      (c->n_qubits > QIDDM_MAX_QUBITS_FUSED && qiddm_capi::wide_cz_adjoint_eligible(c))) {
     // the slabs hold per-layer angle-gradient sums (folded reverse sweep), not K
     const int slots = c->n_qubits <= 8 ? 8 : 16;
     if (c->dtype == QIDDM_F32)

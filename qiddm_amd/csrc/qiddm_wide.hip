@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "qsim_wide_cz.h"
+#include "qsim_wide_cz_adjoint.h"
 
 namespace qiddm_capi {
 
@@ -67,7 +68,66 @@ int launch_t(int n, const void* inputs, const void* tail, void* out, void* ws, c
   }
 }
 
+template <typename T, int N>
+int launch_adj_n(const void* inputs, const void* tail, const void* gout, void* partials, int64_t slab_stride,
+                 void* grad_inputs, int64_t gin_ld, void* ws, const qiddm::KScalars& p, int64_t grid, hipStream_t st) {
+  const int64_t layers = (int64_t)p.n_blocks * p.sel_layers;
+  const size_t smem = qiddm::WideCzAdjSmem<T>::bytes(layers, N);
+  if (smem > kMaxLds)
+    return fail(QIDDM_ERR_UNSUPPORTED, "circuit with %lld layers needs %zu B of LDS for the reverse sweep (limit %zu)",
+                (long long)layers, smem, kMaxLds);
+  auto kern = qiddm::wide_cz_adjoint_kernel<T, N>;
+  static DeviceFlags big_lds_enabled;
+  if (smem > 48 * 1024 && !big_lds_enabled.get()) {
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+    if (ea != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
+    big_lds_enabled.set();
+  }
+  constexpr int NT = qiddm::WideGeom<N>::NT;
+  const int waves = NT >= 4 ? 4 : NT;
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)(waves * qiddm::kWave)), smem, st,
+                     static_cast<const T*>(inputs), static_cast<const T*>(tail), static_cast<const T*>(gout),
+                     static_cast<T*>(partials), slab_stride, static_cast<T*>(grad_inputs), gin_ld,
+                     static_cast<qiddm::V2<T>*>(ws), p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    return fail(QIDDM_ERR_LAUNCH, "wide_cz_adjoint_kernel<n=%d> launch failed: %s", N, hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
+template <typename T>
+int launch_adj_t(int n, const void* inputs, const void* tail, const void* gout, void* partials, int64_t slab_stride,
+                 void* grad_inputs, int64_t gin_ld, void* ws, const qiddm::KScalars& p, int64_t grid, hipStream_t st) {
+  switch (n) {
+#define QIDDM_ADJ_CASE(NN) \
+    case NN: return launch_adj_n<T, NN>(inputs, tail, gout, partials, slab_stride, grad_inputs, gin_ld, ws, p, grid, st);
+    QIDDM_ADJ_CASE(11)
+    QIDDM_ADJ_CASE(12)
+    QIDDM_ADJ_CASE(13)
+    QIDDM_ADJ_CASE(14)
+    QIDDM_ADJ_CASE(15)
+    QIDDM_ADJ_CASE(16)
+#undef QIDDM_ADJ_CASE
+    default: return fail(QIDDM_ERR_UNSUPPORTED, "wide CZ reverse sweep covers 11..16 qubits (got %d)", n);
+  }
+}
+
 }  // namespace
+
+bool wide_cz_adjoint_eligible(const qiddm_circuit_t* c) {
+  static const bool force_tiled = std::getenv("QIDDM_WIDE_TILED") != nullptr;
+  return !force_tiled && wide_cz_eligible(c) && c->n_rounds == 1 && (int64_t)c->n_blocks * c->sel_layers >= 2;
+}
+
+int launch_wide_cz_adjoint(int dtype, int n, const void* inputs, const void* tail, const void* gout, void* partials,
+                           int64_t slab_stride, void* grad_inputs, int64_t gin_ld, void* ws, const qiddm::KScalars& p,
+                           int64_t grid, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return dtype == QIDDM_F32
+             ? launch_adj_t<float>(n, inputs, tail, gout, partials, slab_stride, grad_inputs, gin_ld, ws, p, grid, st)
+             : launch_adj_t<double>(n, inputs, tail, gout, partials, slab_stride, grad_inputs, gin_ld, ws, p, grid, st);
+}
 
 // resident workgroups (= slabs in use): up to four 4-wave workgroups per CU
 int64_t wide_cz_grid(int64_t batch, int64_t slabs) {
