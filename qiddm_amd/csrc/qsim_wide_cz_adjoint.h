@@ -295,30 +295,12 @@ struct WideCzAdj : WideCz<T, N> {
       }
       fl_ex[j] = v;
     }
-    T fr[R], fr_ex[4][R];
     C cs_reg[4], cs_tile[NB];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
       cs_reg[rb] = wide_uniform2<T>(this->s_ry[layer_base * N + (N - 1 - G::local_bit(SET, rb == 0 ? 0 : 6 + rb))]);
 #pragma unroll
     for (int i = 0; i < NB; ++i) cs_tile[i] = wide_uniform2<T>(this->s_ry[layer_base * N + (N - 1 - G::tile_bit(SET, i))]);
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      T v = 1;
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) v *= ((r >> rb) & 1) ? cs_reg[rb].y : cs_reg[rb].x;
-      fr[r] = v;
-#pragma unroll
-      for (int ex = 0; ex < 4; ++ex) {
-        T u = 1;
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-          const bool b = (r >> rb) & 1;
-          u *= rb == ex ? (b ? cs_reg[rb].x : -cs_reg[rb].y) : (b ? cs_reg[rb].y : cs_reg[rb].x);
-        }
-        fr_ex[ex][r] = u;
-      }
-    }
     T acc_common = 0, acc_reg[4] = {0, 0, 0, 0}, acc_tile[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) acc_tile[i] = 0;
@@ -329,21 +311,37 @@ struct WideCzAdj : WideCz<T, N> {
       undo_down_to<SET, 9, 0>(a, l, lcur, th_cur);
       alpha_tile(a, l, t, m);
       undo_diag<SET>(a, l, d, t);
-      // layer 0: d/dtheta_w = Re (RY^dagger lambda)[e_w]
+      // layer 0: d/dtheta_w = Re (RY^dagger lambda)[e_w].  The register bits are contracted level by level: after
+      // level k, pl[] holds the plain contraction of bits 0..k and ex[j][] the one with bit j's factor pair replaced
+      // by its selector pair (-sin, cos) -- five weighted sums for 82 FMAs and no tables
+      T pl[8], ex[4][8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        pl[r] = cs_reg[0].x * l[2 * r].x + cs_reg[0].y * l[2 * r + 1].x;
+        ex[0][r] = cs_reg[0].x * l[2 * r + 1].x - cs_reg[0].y * l[2 * r].x;
+      }
+#pragma unroll
+      for (int k = 1; k < 4; ++k) {
+        const int cnt = 8 >> k;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          if (r < cnt) {
+            const T p0 = pl[2 * r], p1 = pl[2 * r + 1];
+            ex[k][r] = cs_reg[k].x * p1 - cs_reg[k].y * p0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (j < k) ex[j][r] = cs_reg[k].x * ex[j][2 * r] + cs_reg[k].y * ex[j][2 * r + 1];
+            pl[r] = cs_reg[k].x * p0 + cs_reg[k].y * p1;
+          }
+        }
+      }
+      const T s_plain = pl[0];
       T ft = 1;
 #pragma unroll
       for (int i = 0; i < NB; ++i) ft *= ((t >> i) & 1u) ? cs_tile[i].y : cs_tile[i].x;
-      T s_plain = 0;
-#pragma unroll
-      for (int r = 0; r < R; ++r) s_plain += l[r].x * fr[r];
       acc_common += ft * s_plain;
 #pragma unroll
-      for (int ex = 0; ex < 4; ++ex) {
-        T s_ex = 0;
-#pragma unroll
-        for (int r = 0; r < R; ++r) s_ex += l[r].x * fr_ex[ex][r];
-        acc_reg[ex] += ft * s_ex;
-      }
+      for (int exi = 0; exi < 4; ++exi) acc_reg[exi] += ft * ex[exi][0];
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
         T u = 1;

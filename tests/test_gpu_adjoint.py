@@ -243,3 +243,52 @@ def test_wide_qconv_trains_through_the_unitary_gemm_route(c_in, c_out, hw, batch
     assert (layer.weights.grad.cpu() - wo.grad).abs().max().item() < 2e-3 * sw
     sx = max(xo.grad.abs().max().item(), 1e-12)
     assert (xd.grad.cpu() - xo.grad).abs().max().item() < 2e-3 * sx
+
+
+# ---- the pass-structured reverse sweep of the wide CZ family (qsim_wide_cz_adjoint.h) --------------------------------
+@pytest.mark.parametrize("n,L,S,meas,B", [(11, 1, 2, "expz", 3), (11, 3, 1, "probs", 2), (12, 2, 2, "probs", 3),
+                                          (13, 1, 3, "expz", 2), (13, 5, 1, "expz", 2), (14, 2, 2, "expz", 2),
+                                          (16, 1, 2, "expz", 2), (16, 2, 2, "expz", 1)])
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-9), ("f32", 2e-4)])
+def test_wide_cz_adjoint_vs_oracle_autograd(n, L, S, meas, B, precision, tol):
+    """Weights and angle inputs against autograd through the oracle: even / odd layer counts (the turnaround runs on
+    either local-bit set), every layer a block start (S = 1), both read-outs, 11 .. 16 qubits, both precisions."""
+    from oracle import circuits as oc
+    from qiddm_amd.circuit import Circuit, run_adjoint
+    if n == 16 and (precision == "f64" or L * S > 2) and meas == "probs":
+        pytest.skip("oracle time")
+    g_ = torch.Generator().manual_seed(1000 * n + 10 * L + S)
+    circ = Circuit(n_qubits=n, encoding="rz", imprimitive="CZ", measure=meas, n_rounds=1, n_blocks=L, sel_layers=S)
+    w = torch.randn(circ.angles_shape, generator=g_, dtype=torch.float64) * 0.6
+    x = torch.rand(B, n, generator=g_, dtype=torch.float64) * 2 - 1
+    g = torch.randn(B, (1 << n) if meas == "probs" else n, generator=g_, dtype=torch.float64)
+    wo, xo = w.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    out = oc.run_circuit(oc.Spec(n=n, encoding="rz", imprimitive="CZ", measure=meas), xo, wo)
+    (out * g).sum().backward()
+    ga, gi = run_adjoint(circ, x.cuda(), w.cuda(), g.cuda(), precision)
+    sw = max(wo.grad.abs().max().item(), 1e-12)
+    assert (ga.cpu() - wo.grad).abs().max().item() < tol * sw, (ga.cpu() - wo.grad).abs().max().item() / sw
+    # one block: the data enters only through the first RZ layer on |0..0>, a global phase (finding F2) -- the input
+    # gradient is exactly zero and the oracle's is rounding noise, hence the floor on the scale
+    sx = max(xo.grad.abs().max().item(), 1e-3)
+    assert (gi.cpu() - xo.grad).abs().max().item() < tol * sx, (gi.cpu() - xo.grad).abs().max().item() / sx
+    if L == 1:
+        assert gi.abs().max().item() == 0.0
+
+
+def test_wide_cz_adjoint_many_samples_and_determinism():
+    """More samples than resident workgroups (slab pairs and accumulators are reused sample after sample); the summed
+    weight gradient equals the sum of per-chunk gradients and is bit-reproducible (fixed-order sums)."""
+    from qiddm_amd.circuit import Circuit, run_adjoint
+    torch.manual_seed(5)
+    n, B = 12, 700
+    circ = Circuit(n_qubits=n, encoding="rz", imprimitive="CZ", measure="expz", n_rounds=1, n_blocks=2, sel_layers=2)
+    w = (torch.randn(circ.angles_shape, dtype=torch.float64) * 0.5).cuda()
+    x = (torch.rand(B, n, dtype=torch.float64) * 2 - 1).cuda()
+    g = torch.randn(B, n, dtype=torch.float64).cuda()
+    ga, gi = run_adjoint(circ, x, w, g, "f64")
+    ga2, gi2 = run_adjoint(circ, x, w, g, "f64")
+    assert torch.equal(ga, ga2) and torch.equal(gi, gi2)
+    parts = [run_adjoint(circ, x[i:i + 175], w, g[i:i + 175], "f64") for i in range(0, B, 175)]
+    assert torch.allclose(ga, sum(p[0] for p in parts), atol=1e-9)
+    assert torch.allclose(gi, torch.cat([p[1] for p in parts]), atol=1e-12)
