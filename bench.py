@@ -171,7 +171,11 @@ def timed_region(runner, steps, warmup, world, dev):
     runner.prepare(warmup)
     runner.run(warmup)
     torch.cuda.synchronize()
-    # calibrate the repeat count on one untimed pass of the K steps (every rank must use the same count)
+    # calibrate the repeat count on untimed passes of the K steps (the first replay of a fresh graph is slow: time the
+    # third); every rank must use the same count
+    for _ in range(2):
+        runner.run(steps)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     runner.run(steps)
     torch.cuda.synchronize()
@@ -277,6 +281,14 @@ def c5_roofline(dev):
     x = torch.randn(batch, n, device=dev)
     table = prepare_gates(circ, w, "f32")
     us = _event_time_us(lambda: run_forward(circ, x, w, "f32", table=table), iters=5, warm=2)
+    # the reverse sweep of ONE round of the same shard (weights + input gradients; wide_cz_adjoint_kernel)
+    try:
+        from qiddm_amd.circuit import run_adjoint
+        one = Circuit(n_qubits=n, encoding="rz", imprimitive="CZ", measure="expz", n_rounds=1, n_blocks=6, sel_layers=2)
+        g = torch.randn(batch, n, device=dev)
+        adj_us = _event_time_us(lambda: run_adjoint(one, x, w[0:1], g, "f32"), iters=3, warm=1)
+    except Exception as e:  # pragma: no cover
+        adj_us = repr(e)
     sweeps, kernel = wide_sweeps_per_sample(circ, "f32")
     sweep_bytes = sweeps * 2 * 8 * (1 << n) * batch                    # read + write of every complex64 amplitude
     alg = circ.algorithmic_bytes_per_sample("f32") * batch
@@ -286,6 +298,7 @@ def c5_roofline(dev):
             "kernel_avg_us": us, "circuits_per_s": batch / (us * 1e-6),
             "gate_apps_per_s": batch * circ.gate_count() / (us * 1e-6),
             "sweeps_per_sample": sweeps, "sweep_bytes_per_launch": sweep_bytes,
+            "adjoint_one_round_us": adj_us,
             "hbm_equivalent": {"bytes_per_launch": alg, "GBps": alg / (us * 1e-6) / 1e9,
                                "note": "SURVEY 8d per-gate model (16*2^n B per gate application); exceeds the HBM peak "
                                        "because one sweep applies a whole layer"},

@@ -31,9 +31,12 @@ run wide_stats --kernel-trace --stats --output-format csv -d $OUT/wide_stats -- 
 run wide_rd --pmc FETCH_SIZE --output-format csv -d $OUT/wide/pmc_rd -- $WIDE
 run wide_wr --pmc WRITE_SIZE --output-format csv -d $OUT/wide/pmc_wr -- $WIDE
 run wide_l2 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/wide_l2 -- $WIDE
+run unet_stats --kernel-trace --stats --output-format csv -d $OUT/unet_stats -- python3 $ROOT/tools/profile_unet_train.py 256 --no-table
 run wide_sq --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES --output-format csv -d $OUT/wide_sq -- $WIDE
 find $OUT/bench_stats -name "*kernel_stats.csv" -exec cp {} $S/bench_kernel_stats.csv \;
 find $OUT/wide_stats -name "*kernel_stats.csv" -exec cp {} $S/wide_kernel_stats.csv \;
+find $OUT/unet_stats -name "*kernel_stats.csv" -exec cp {} $S/unet_simple_training_b256_kernel_stats.csv \;
+grep -h "training step\|recorded in" $OUT/unet_stats.log > $S/unet_simple_training_b256.txt
 python3 $ROOT/tools/pmc_traffic.py $OUT/bench > $S/bench_pmc_traffic.json 2>> $OUT/rc.log
 python3 $ROOT/tools/pmc_traffic.py $OUT/wide > $S/wide_pmc_traffic.json 2>> $OUT/rc.log
 python3 $ROOT/tools/pmc_reduce.py $OUT/wide_l2 > $S/wide_pmc_l2.json 2>> $OUT/rc.log

@@ -4,8 +4,8 @@
 
     rocprofv3 --kernel-trace --stats --output-format csv -d <out> -- python3 tools/profile_wide.py [what ...]
 
-what: c5 (tiled n=16 forward, 1024 samples)  c4gemm (12-qubit QConv2d eval GEMM)  adjoint (n=8 / n=10 backward)
-      wideadj (n=12 / n=16 wide adjoint)  engine (circuit_kernel<float,8> / <float,10> at batch 65536, dense_quad at 256)
+what: c5 (n=16 forward, 1024 samples: wide_cz_kernel; QIDDM_WIDE_TILED=1 -> the generic tiled kernel)  c4gemm (12-qubit QConv2d eval GEMM)  adjoint (n=8 / n=10 backward)
+      wideadj (n=12 / n=16 reverse sweep, 1024 samples, one round: wide_cz_adjoint_kernel)  engine (circuit_kernel<float,8> / <float,10> at batch 65536, dense_quad at 256)
 """
 import os
 import sys
@@ -49,7 +49,7 @@ def adjoint(iters=3):
 
 
 def wideadj(iters=2):
-    for n, B in ((12, 1024), (16, 128)):
+    for n, B in ((12, 1024), (16, 1024)):
         circ = Circuit(n_qubits=n, encoding="rz", imprimitive="CZ", measure="expz", n_blocks=6, sel_layers=2)
         w = (torch.randn(circ.angles_shape, dtype=torch.float64) * 0.4).to(DEV)
         x = torch.rand(B, n, device=DEV)
