@@ -112,14 +112,15 @@ int64_t qiddm_gate_count(const qiddm_circuit_t *circ);
  * num_rot_gates * 7 variants * 8 reals, plus (n <= 10) the folded per-layer tables the forward of a
  * CZ circuit runs on: per layer n (cos, sin)(theta/2) pairs and 2^min(n,6) + 2^max(n-6,0) phases
  * exp(i sum +-(phi^l + omega^(l-1))/2) -- RZ(phi) RZ(omega) and the CZ ring between two RY layers
- * are one diagonal                                                                       */
+ * are one diagonal; for n = 11..16 CZ circuits with no / RZ encoding, per layer and wire the pairs
+ * (cos, sin)(theta/2) and (cos, sin)((phi^l + omega^(l-1))/2) the pass-structured kernels run on      */
 int64_t qiddm_gate_table_elems(const qiddm_circuit_t *circ);
 /* replicas of a full parameter-shift sweep: 6*num_rot_gates (+ 2*n_blocks*n for the
  * input angles of RZ/RY encodings)                                                       */
 int64_t qiddm_num_shift_replicas(const qiddm_circuit_t *circ, int with_inputs);
 /* bytes of device workspace qiddm_forward (n_replicas = 0) / qiddm_forward_shifted need for this
- * circuit and batch: 0 for n <= 10 (register-resident slabs); for n = 11..16 one 2^n-amplitude slab
- * per concurrently resident workgroup (it stays L2 / Infinity-Cache resident).                   */
+ * circuit and batch: 0 for n <= 10 (register-resident slabs); for n = 11..16 2^n-amplitude slabs for
+ * the concurrently resident workgroups (up to 1024: the sweeps of a 16-qubit shard are HBM traffic).  */
 int64_t qiddm_workspace_bytes(const qiddm_circuit_t *circ, int64_t batch, int64_t n_replicas);
 
 /* ---- gate table ----------------------------------------------------------
@@ -181,7 +182,9 @@ int qiddm_backward_adjoint(const qiddm_circuit_t *circ, const void *inputs, int6
                            int64_t in_ld, const void *gate_table, const void *grad_out, int64_t g_ld,
                            void *k_partials, void *grad_inputs, int64_t gin_ld, void *stream);
 /* n = 11..16: the same gradient with psi and lambda in a per-workgroup slab pair of `workspace`
- * (qiddm_adjoint_workspace_bytes; 0 for n <= 10), one sweep per gate.  Same K slabs, same finalize.     */
+ * (qiddm_adjoint_workspace_bytes; 0 for n <= 10).  CZ circuits with no / RZ encoding and >= 2 layers: the
+ * pass-structured reverse sweep (one sweep of both slabs per LAYER; the slabs of k_partials then hold per-layer
+ * angle-gradient sums: opaque, hand them to qiddm_adjoint_finalize); everything else: one sweep per gate, K slabs. */
 int64_t qiddm_adjoint_workspace_bytes(const qiddm_circuit_t *circ, int64_t batch);
 int qiddm_backward_adjoint_wide(const qiddm_circuit_t *circ, const void *inputs, int64_t batch,
                                 int64_t in_ld, const void *gate_table, const void *grad_out, int64_t g_ld,
@@ -402,6 +405,8 @@ int qiddm_upsample2x_backward(const double *grad_y, int64_t planes, int64_t heig
  *   rows: (C kh kw + 1, 2 row_channels) float32 -- rows[j][c] = Re U[2c,j], rows[j][row_channels + c] = Im U[2c,j],
  *         last row 0.5 sum_{j >= C kh kw} U[2c,j]; zero for c >= out_channels.  row_channels in {8, 16, 32}
  *         (C kh kw <= 510): wider layers return QIDDM_ERR_UNSUPPORTED (use qiddm_qconv_backward or library GEMMs).
+ *         From 32 patch features on the three products run on the f32 matrix cores (v_mfma_f32_16x16x4_f32 /
+ *         32x32x2_f32); numel(x) and numel(grad_y) must then be below 2^32 (32-bit element offsets).
  * qiddm_matrix_adjoint: K slabs (-> qiddm_adjoint_finalize) of 2 Re <lambda_s| dU/dangle |psi0_s> summed over
  * `count` (psi0, lambda) pairs of complex128 vectors (count, 2^n, interleaved); circ->dtype QIDDM_F64, gate table
  * of that dtype, 2 <= n_qubits <= 16.                                                                        */

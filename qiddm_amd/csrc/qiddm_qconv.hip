@@ -299,7 +299,10 @@ int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch,
   // kernel experiments (A/B on the same box)
   static const bool env_mfma = std::getenv("QIDDM_QCONV_MFMA") != nullptr;
   static const bool env_valu = std::getenv("QIDDM_QCONV_VALU") != nullptr;
-  const bool force_valu = env_valu || (f < 32 && !env_mfma);
+  // the MFMA kernel addresses x and grad_y with 32-bit element offsets
+  const bool fits32 = batch * in_channels * height * width < ((int64_t)1 << 32) &&
+                      batch * out_channels * ho * wo < ((int64_t)1 << 32);
+  const bool force_valu = env_valu || !fits32 || (f < 32 && !env_mfma);
   const int jbm = (int)((qiddm::tm_fcols((int)f) / 16 + qiddm::kTmWaves - 1) / qiddm::kTmWaves);
 #define QIDDM_TM_CASE(CO, J)                                                                                     \
   if (!kern && !force_valu && row_channels == CO && jbm <= J && qiddm::tm_lds_bytes<CO>((int)f) <= kMaxLds) {   \
