@@ -98,6 +98,30 @@ int launch(const Ptrs& ptr, const qiddm::KScalars& p, int64_t n_replicas, hipStr
     return fail(QIDDM_ERR_UNSUPPORTED,
                 "circuit with %lld Rot gates needs %zu B of LDS for its gate table (limit %zu)",
                 (long long)n_rot, smem, kMaxLds);
+  if constexpr (!SHIFT && N >= 8) {
+    // forward of a CZ circuit with no / RZ encoding at the wide register-resident sizes: the lean folded-only kernel
+    // (100 / 134 / 206 VGPRs at n = 8 / 9 / 10 -> 4 / 3 / 2 waves per SIMD; the all-paths kernel: 235 / 255+34 / 256+205)
+    static const bool all_paths = std::getenv("QIDDM_NO_LEAN") != nullptr;   // kernel experiments: A/B
+    // ... when there is more than one wave of work per SIMD: below that the all-paths kernel's one-layer-ahead table
+    // prefetch wins (n = 10, 256 samples: 69.8 vs 76.5 us; 4096: 274 vs 245; 65 536: 4.18 vs 3.68 ms, gpurun_out/r02g)
+    if (p.fold && p.encoding != QIDDM_ENC_AMPLITUDE && !all_paths && groups > 1024) {
+      auto kf = qiddm::circuit_folded_kernel<T, N>;
+      static qiddm_capi::DeviceFlags big_lds_folded;
+      if (smem > 48 * 1024 && !big_lds_folded.get()) {
+        const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kf),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+        if (ea != hipSuccess)
+          return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
+        big_lds_folded.set();
+      }
+      hipLaunchKernelGGL(kf, grid, dim3(waves * qiddm::kWave), smem, stream, static_cast<const T*>(ptr.inputs),
+                         static_cast<const T*>(ptr.table), static_cast<T*>(ptr.out), p);
+      const hipError_t ef = hipGetLastError();
+      if (ef != hipSuccess)
+        return fail(QIDDM_ERR_LAUNCH, "circuit_folded_kernel<n=%d> launch failed: %s", N, hipGetErrorString(ef));
+      return QIDDM_OK;
+    }
+  }
   auto kern = qiddm::circuit_kernel<T, N, SHIFT>;
   static qiddm_capi::DeviceFlags big_lds_enabled;  // benign race: the attribute call is idempotent
   if (smem > 48 * 1024 && !big_lds_enabled.get()) {

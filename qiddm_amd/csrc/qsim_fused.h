@@ -490,6 +490,66 @@ struct Engine {
     }
   }
 
+  // the same round with the wave-uniform table entries (RY coefficients, register-bit phases) held in SCALAR registers
+  // and no one-layer-ahead copy of the tables: ~100 fewer VGPRs at n = 10, which is what lets circuit_folded_kernel run
+  // two waves per SIMD (the other wave hides the LDS latency the prefetch used to hide)
+  __device__ __forceinline__ static T uni(T v) {
+    if constexpr (sizeof(T) == 4) {
+      return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+    } else {
+      return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                              __builtin_amdgcn_readfirstlane(__double2loint(v)));
+    }
+  }
+  template <int W>
+  __device__ __forceinline__ void ry_wires_u(C (&a)[R], const C* __restrict__ base) const {
+    if constexpr (W < N) {
+      constexpr int Q = N - 1 - W;
+      const C csw = base[W];
+      const T c = uni(csw.x), s = uni(csw.y);
+      if constexpr (kind_of<W>() == kReg) {
+        ry_pairs<(1 << (Q >= LB ? Q - LB : 0))>(a, c, s);
+      } else if constexpr (kind_of<W>() == kSwap) {
+        swap_reg0_with_lane_bit<Q>(a);
+        ry_pairs<1>(a, c, s);
+        swap_reg0_with_lane_bit<Q>(a);
+      } else {
+        const T sg = ((llane >> Q) & 1) ? s : -s;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const C par = xlane2<(1 << Q), T>(a[r], lane);
+          a[r] = __builtin_elementwise_fma(bcast<T>(sg), par, bcast<T>(c) * a[r]);
+        }
+      }
+      ry_wires_u<W + 1>(a, base);
+    }
+  }
+  __device__ __forceinline__ void folded_round_u(const KScalars& p, C (&a)[R], const C (&dx)[R], int first_layer) const {
+    const int layers = p.n_blocks * p.sel_layers;
+    for (int li = 0; li < layers; ++li) {
+      const int s = li % p.sel_layers;
+      const C* __restrict__ base = reinterpret_cast<const C*>(s_gates + (size_t)(first_layer + li) * S::kFoldStride);
+      const C tlo = base[N + sub];
+      // the CZ ring of the PREVIOUS layer of the round (none in front of a round's first layer)
+      const int prev_ri = li == 0 ? -1 : ((li - 1) % p.sel_layers) % (N > 1 ? N - 1 : 1);
+      const uint32_t cz = (N > 1 && prev_ri >= 0) ? s_cz[prev_ri * kWave + llane] : 0u;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        C ph = tlo;
+        if constexpr (R > 1) {
+          const C th = base[N + LPS + r];
+          const C thu = C{uni(th.x), uni(th.y)};
+          ph = cmul2<T>(thu, ph, times_i<T>(ph));
+        }
+        if (s == 0 && p.encoding == 2) ph = cmul2<T>(dx[r], ph, times_i<T>(ph));  // block start: data re-upload
+        C v = cmul2<T>(ph, a[r], times_i<T>(a[r]));
+        const uint32_t sb = ((cz >> r) & 1u) << 31;
+        a[r] = C{flip_sign(v.x, sb), flip_sign(v.y, sb)};
+      }
+      ry_wires_u<0>(a, base);
+    }
+  }
+
   // -- single-qubit gate between register pairs (r, r|J); matrix halves
   //    lo = [u00,iu00,u01,iu01] (row of the bit-clear amplitude), hi = [u11,iu11,u10,iu10]
   template <int J>
@@ -822,6 +882,46 @@ struct Engine {
       }
     }
   }
+
+  // -- the same for CZ circuits with no / RZ encoding on the folded tables ONLY: nothing of the general gate path, the
+  //    CNOT scatter or the amplitude embedding is compiled in, which is what lets the n = 9 / 10 forward fit two
+  //    waves per SIMD (circuit_folded_kernel) ---------------------------------------------------------------------
+  __device__ __forceinline__ void run_folded(const KScalars& p, T (&xs)[N], T (&result)[N], T (&pr)[R]) const {
+    C a[R];
+    C dx[R];
+    T cs[N], sn[N];
+    for (int round = 0; round < p.n_rounds; ++round) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) a[r] = C{(T)0, (T)0};
+      a[0] = C{sub == 0 ? (T)1 : (T)0, (T)0};
+      if (p.encoding == 2) {
+        half_angle_sincos(xs, cs, sn);
+        rz_diagonal(cs, sn, dx);
+      }
+      folded_round_u(p, a, dx, round * p.n_blocks * p.sel_layers);
+#pragma unroll
+      for (int r = 0; r < R; ++r) pr[r] = a[r].x * a[r].x + a[r].y * a[r].y;
+      if (p.measure == 1) {
+#pragma unroll
+        for (int w = 0; w < N; ++w) {
+          const int q = N - 1 - w;
+          T acc = 0;
+#pragma unroll
+          for (int r = 0; r < R; ++r) acc += ((((r << LB) | sub) >> q) & 1) ? -pr[r] : pr[r];
+          result[w] = group_sum<T, LB>(acc, lane);
+        }
+      }
+      if (round + 1 < p.n_rounds) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+          const T v = (p.measure == 1)
+                          ? result[j]
+                          : __shfl(pr[0], logical_lane((llane & ~(LPS - 1)) | (j & (LPS - 1))), kWave);
+          xs[j] = v * (T)p.enc_scale;
+        }
+      }
+    }
+  }
 };
 
 // CZ entanglers and no RY data encoding: the circuit can run on the folded tables
@@ -937,6 +1037,60 @@ __global__ __launch_bounds__(4 * kWave) void circuit_kernel(const T* __restrict_
         for (int w = 0; w < N; ++w) acc += gout[sample * p.g_ld + w] * result[w];
       }
       if (valid && sub == 0) dots[(int64_t)replica_local * p.batch + sample] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// circuit kernel for CZ circuits with no / RZ encoding, forward only, on the folded tables: the lean sibling of
+// circuit_kernel<T, N, false> for the wide register-resident sizes (n = 9, 10).  Round-2 counters
+// (profiles/r02a/wide_pmc_sq.json): the all-paths kernel needs 256 VGPRs + 205 AGPRs at n = 10 -> ONE wave per SIMD,
+// where it sits at 86 % of the single-wave issue cap (one VALU instruction per 4 cycles) = 35 % of the vector peak.
+// ---------------------------------------------------------------------------
+template <typename T, int N>
+__global__ __launch_bounds__(4 * kWave, (sizeof(T) == 4 ? 2 : 1)) void circuit_folded_kernel(const T* __restrict__ inputs,
+                                                                      const T* __restrict__ table,
+                                                                      T* __restrict__ out, const KScalars p) {
+  using E = Engine<T, N>;
+  using L = typename E::L;
+  constexpr int LB = L::LB, R = L::R, SPW = L::SPW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int n_rot = p.n_rounds * p.n_blocks * p.sel_layers * N;
+  E eng;
+  eng.carve(smem_raw, n_rot);
+  eng.fill_folded_from_table(table + (size_t)n_rot * kVariants * kGateReals, n_rot / N);
+  eng.fill_rings(false);
+  __syncthreads();
+  const int sub = eng.sub;
+  const int wave = threadIdx.x >> 6;
+  const int swave = eng.llane >> LB;
+  const int64_t groups = (p.batch + SPW - 1) / SPW;
+  const int waves_per_block = blockDim.x >> 6;
+  for (int64_t grp = (int64_t)blockIdx.x * waves_per_block + wave; grp < groups;
+       grp += (int64_t)gridDim.x * waves_per_block) {
+    const int64_t sample_raw = grp * SPW + swave;
+    const bool valid = sample_raw < p.batch;
+    const int64_t sample = valid ? sample_raw : p.batch - 1;
+    T xs[N];
+    if (p.encoding >= 2) {
+#pragma unroll
+      for (int j = 0; j < N; ++j) xs[j] = inputs[sample * p.in_ld + j] * (T)p.enc_scale;
+    } else {
+#pragma unroll
+      for (int j = 0; j < N; ++j) xs[j] = (T)0;
+    }
+    T result[N], pr[R];
+    eng.run_folded(p, xs, result, pr);
+    if (p.measure == 0) {
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) out[sample * p.out_ld + ((r << LB) | sub)] = pr[r];
+      }
+    } else {
+      T v = 0;  // arithmetic select (see half_angle_sincos)
+#pragma unroll
+      for (int w = 0; w < N; ++w) v = fma((T)(sub == w ? 1 : 0), result[w], v);
+      if (valid && sub < N) out[sample * p.out_ld + sub] = v;
     }
   }
 }

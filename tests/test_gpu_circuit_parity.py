@@ -177,3 +177,24 @@ def test_errors_are_loud():
                     torch.zeros(2, 5).cuda(), torch.zeros(1, 1, 1, 2, 3, dtype=torch.float64).cuda())
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         run_forward(Circuit(n_qubits=2), torch.zeros(2, 2), torch.zeros(1, 1, 1, 2, 3))
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("n,meas,N,L,S", [(8, "expz", 1, 1, 14), (8, "probs", 2, 3, 2), (9, "expz", 2, 2, 2), (9, "probs", 1, 3, 1),
+                                          (10, "probs", 2, 3, 2), (10, "expz", 1, 2, 9)])
+def test_lean_folded_forward_large_batches(n, meas, N, L, S, precision):
+    """More than one wave of work per SIMD (> 1024 sample groups) sends the forward of a CZ circuit with RZ encoding
+    through circuit_folded_kernel (scalar-register tables, 2-4 waves per SIMD): chained rounds, every entangler
+    range (S = 9 at n = 10, 14 layers at n = 8), both read-outs, a ragged batch; 48 rows spread over the batch against
+    the oracle, all rows normalised."""
+    batch = 1500 + n
+    circ, spec, x, w = _mk(n, "rz", "CZ", meas, N=N, L=L, S=S, batch=batch, seed=7000 + 10 * n + S)
+    got = _run(circ, x, w, precision)
+    idx = torch.linspace(0, batch - 1, 48).long()
+    ref = _oracle(spec, x[idx], w)
+    tol = F64_TOL if precision == "f64" else F32_TOL
+    assert torch.allclose(got[idx], ref, **tol), (got[idx] - ref).abs().max()
+    if meas == "probs":
+        assert torch.allclose(got.sum(1), torch.ones(batch, dtype=torch.float64), atol=1e-5)
+    else:
+        assert got.abs().max() <= 1 + 1e-5
