@@ -38,6 +38,14 @@ int64_t wide_cz_grid(int64_t batch, int64_t slabs);
 // pass-structured reverse sweep (qsim_wide_cz_adjoint.h): one round of >= 2 layers of that family.
 // QIDDM_WIDE_TILED=1 keeps the generic per-gate kernels (kernel experiments: A/B on the same box)
 bool wide_cz_adjoint_eligible(const qiddm_circuit_t* c);
+// register-resident reverse sweep of 10-qubit CZ circuits (qsim_cz10_adjoint.h): one round of >= 2 layers
+bool cz10_adjoint_eligible(const qiddm_circuit_t* c);
+// 10-qubit CZ circuits with no / RZ encoding carry BOTH tails behind the gate variants: the folded tables of the n <= 10
+// forward, then the per-wire tables (2n entries per layer) of the reverse sweep
+inline bool cz10_tables(const qiddm_circuit_t* c) {
+  return c->n_qubits == 10 && c->imprimitive == QIDDM_IMP_CZ &&
+         (c->encoding == QIDDM_ENC_NONE || c->encoding == QIDDM_ENC_RZ);
+}
 
 }  // namespace qiddm_capi
 
@@ -50,4 +58,7 @@ int launch_wide_cz(int dtype, int n, const void* inputs, const void* tail, void*
 int launch_wide_cz_adjoint(int dtype, int n, const void* inputs, const void* tail, const void* gout, void* partials,
                            int64_t slab_stride, void* grad_inputs, int64_t gin_ld, void* ws, const qiddm::KScalars& p,
                            int64_t grid, void* stream);
+int launch_cz10_adjoint(int dtype, const void* inputs, const void* tail, const void* gout, void* partials,
+                        int64_t slab_stride, void* grad_inputs, int64_t gin_ld, const qiddm::KScalars& p, int64_t grid,
+                        void* stream);
 }  // namespace qiddm_capi

@@ -617,7 +617,9 @@ static int64_t fold_entries(const qiddm_circuit_t* c, int64_t n_rot) {
   if (c->n_qubits > QIDDM_MAX_QUBITS_FUSED)   // wide CZ forward: (cos, sin)(theta/2) and (cos, sin)(alpha/2) per layer and wire
     return qiddm_capi::wide_cz_eligible(c) ? 2 * n_rot : 0;
   const int n = c->n_qubits, lb = n < 6 ? n : 6;
-  return (n_rot / n) * (n + ((int64_t)1 << lb) + ((int64_t)1 << (n - lb)));
+  int64_t e = (n_rot / n) * (n + ((int64_t)1 << lb) + ((int64_t)1 << (n - lb)));
+  if (qiddm_capi::cz10_tables(c)) e += 2 * n_rot;   // + the per-wire tables of cz10_adjoint_kernel
+  return e;
 }
 
 int64_t qiddm_gate_table_elems(const qiddm_circuit_t* c) {
@@ -862,6 +864,18 @@ int qiddm_backward_adjoint(const qiddm_circuit_t* c, const void* inputs, int64_t
   ad.want_inputs = (grad_inputs != nullptr && c->encoding != QIDDM_ENC_NONE) ? 1 : 0;
   ad.pad_ = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (batch > 0 && qiddm_capi::cz10_adjoint_eligible(c)) {
+    // register-resident folded reverse sweep; the slabs then hold per-layer angle-gradient sums (finalize knows)
+    const int64_t n_rot = (int64_t)c->n_blocks * c->sel_layers * c->n_qubits;
+    const int64_t layers = n_rot / c->n_qubits;
+    const size_t esz = c->dtype == QIDDM_F32 ? 4 : 8;
+    const int64_t fold_reals = 2 * layers * (10 + 64 + 16);
+    const char* tail = static_cast<const char*>(gate_table) +
+                       ((size_t)n_rot * qiddm::kVariants * qiddm::kGateReals + (size_t)fold_reals) * esz;
+    return qiddm_capi::launch_cz10_adjoint(c->dtype, inputs, tail, grad_out, k_partials, n_rot * 8,
+                                           ad.want_inputs ? grad_inputs : nullptr, gin_ld, p, adjoint_blocks_n(10, batch),
+                                           stream);
+  }
   // batch == 0 still has to zero the (single) partial slab: launch with no samples
   const ConvPtrs none;
   return c->dtype == QIDDM_F32
@@ -951,7 +965,8 @@ int qiddm_adjoint_finalize(const qiddm_circuit_t* c, const double* angles, const
   const unsigned blocks = (unsigned)n_rot;  // one wavefront per gate
   hipStream_t st = static_cast<hipStream_t>(stream);
   if ((make_params(c).fold && c->n_qubits >= 2 && c->n_qubits <= qiddm::kFoldedAdjointMaxQubits) ||
-      (c->n_qubits > QIDDM_MAX_QUBITS_FUSED && qiddm_capi::wide_cz_adjoint_eligible(c))) {
+      (c->n_qubits > QIDDM_MAX_QUBITS_FUSED && qiddm_capi::wide_cz_adjoint_eligible(c)) ||
+      qiddm_capi::cz10_adjoint_eligible(c)) {
     // the slabs hold per-layer angle-gradient sums (folded reverse sweep), not K
     const int slots = c->n_qubits <= 8 ? 8 : 16;
     if (c->dtype == QIDDM_F32)

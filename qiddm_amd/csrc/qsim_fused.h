@@ -1308,6 +1308,13 @@ __global__ void prepare_gates_kernel(const double* __restrict__ angles, T* __res
     }
     const int lb = n < 6 ? n : 6;
     const int e_per_layer = n + (1 << lb) + (1 << (n - lb));
+    const int64_t n_layers = n_rot / n;
+    if (j >= n_layers * e_per_layer) {  // n = 10 CZ circuits: the per-wire tables of cz10_adjoint_kernel behind them
+      const int64_t j2 = j - n_layers * e_per_layer;
+      const int layer2 = (int)(j2 / (2 * n)), e2 = (int)(j2 - (int64_t)layer2 * 2 * n);
+      wide_fold_entry<T>(angles, n, layer2, layer2 % layers_per_round, e2, table + n_rot * kVariants * kGateReals + 2 * j);
+      return;
+    }
     const int layer = (int)(j / e_per_layer), e = (int)(j - (int64_t)layer * e_per_layer);
     folded_entry<T>(angles, n, lb, layer, layer % layers_per_round, e,
                     table + n_rot * kVariants * kGateReals + (size_t)layer * 2 * e_per_layer + 2 * e);

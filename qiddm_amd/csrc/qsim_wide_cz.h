@@ -166,7 +166,7 @@ struct WideCz {
   struct Diag {
     C pl;            // lane part of the phase
     C pr[R];         // register part (wave-uniform: lives in scalar registers for float)
-    C ut[NB];        // unit phases of the tile bits (wave-uniform)
+    C ut[NB > 0 ? NB : 1];   // unit phases of the tile bits (wave-uniform)
     uint32_t kl, rl;  // this lane's index bits and their ring rotation
     uint32_t rr_reg[R];  // ring rotation of the register bits' index contribution (wave-uniform)
     int range;
@@ -250,7 +250,7 @@ struct WideCz {
   struct Init {
     T fl;        // lane part
     T fr[R];     // register part
-    C ft[NB];    // (cos, sin) of the tile bits' wires (wave-uniform)
+    C ft[NB > 0 ? NB : 1];   // (cos, sin) of the tile bits' wires (wave-uniform)
   };
   template <int SET>
   __device__ __forceinline__ void build_init(int layer0, Init& in) const {
@@ -290,7 +290,7 @@ struct WideCz {
   struct Meas {
     T tot = 0;
     T reg[4] = {0, 0, 0, 0};
-    T tile[NB];
+    T tile[NB > 0 ? NB : 1];
   };
   template <int SET>
   __device__ __forceinline__ void measure_tile(const C (&a)[R], uint32_t t, int measure, T* __restrict__ out_row,

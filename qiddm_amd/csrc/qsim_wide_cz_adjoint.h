@@ -46,15 +46,24 @@ struct WideCzAdj : WideCz<T, N> {
   //      Re <l| (-iY) |a>, evaluated before the un-application ---------------------------------------------------
   template <int J>
   __device__ __forceinline__ void undo_pairs(C (&a)[R], C (&l)[R], T c, T s, T& th) const {
+    // two FMA chains (no product temporaries: written as sums of products the scheduler hoists every multiply and the
+    // kernel needs 500 registers), each pair un-applied right after its contribution
+    T t0 = 0, t1 = 0;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if ((r & J) == 0) {
         const C a0 = a[r], a1 = a[r | J], l0 = l[r], l1 = l[r | J];
-        th += (l1.x * a0.x + l1.y * a0.y) - (l0.x * a1.x + l0.y * a1.y);
+        t0 = fma(l1.x, a0.x, t0);
+        t1 = fma(l1.y, a0.y, t1);
+        t0 = fma(-l0.x, a1.x, t0);
+        t1 = fma(-l0.y, a1.y, t1);
+        a[r] = __builtin_elementwise_fma(bcast<T>(s), a1, bcast<T>(c) * a0);
+        a[r | J] = __builtin_elementwise_fma(bcast<T>(-s), a0, bcast<T>(c) * a1);
+        l[r] = __builtin_elementwise_fma(bcast<T>(s), l1, bcast<T>(c) * l0);
+        l[r | J] = __builtin_elementwise_fma(bcast<T>(-s), l0, bcast<T>(c) * l1);
       }
     }
-    this->eng.template ry_pairs<J>(a, c, -s);
-    this->eng.template ry_pairs<J>(l, c, -s);
+    th += t0 + t1;
   }
   template <int POS>
   __device__ __forceinline__ void undo_pos(C (&a)[R], C (&l)[R], T c, T s, T& th) const {
@@ -64,15 +73,17 @@ struct WideCzAdj : WideCz<T, N> {
       constexpr int LBIT = POS - 1;
       const bool hi = (this->llane >> LBIT) & 1;
       const T sg = hi ? -s : s;   // RY^dagger = [[c, s], [-s, c]]
+      T tc = 0;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const C pa = xlane2<(1 << LBIT), T>(a[r], this->lane);
         const C pl = xlane2<(1 << LBIT), T>(l[r], this->lane);
-        const T cross = l[r].x * pa.x + l[r].y * pa.y;   // own lambda with the partner's psi
-        th += hi ? cross : -cross;
+        tc = fma(l[r].x, pa.x, tc);   // own lambda with the partner's psi
+        tc = fma(l[r].y, pa.y, tc);
         a[r] = __builtin_elementwise_fma(bcast<T>(sg), pa, bcast<T>(c) * a[r]);
         l[r] = __builtin_elementwise_fma(bcast<T>(sg), pl, bcast<T>(c) * l[r]);
       }
+      th += hi ? tc : -tc;
     } else if constexpr (POS <= 6) {
       constexpr int LBIT = POS - 1;
       this->eng.template swap_reg0_with_lane_bit<LBIT>(a);
@@ -89,7 +100,13 @@ struct WideCzAdj : WideCz<T, N> {
   __device__ __forceinline__ void undo_down_to(C (&a)[R], C (&l)[R], int layer, T (&th)[10]) const {
     if constexpr (POS >= FROM) {
       const C cs = this->template ry_coeff<SET, POS>(layer);
-      undo_pos<POS>(a, l, cs.x, cs.y, th[POS]);
+      T c = cs.x;
+      // Ordering token.  The reduction th[POS + 1] is off the critical path, so the scheduler parks it -- with the 64
+      // registers of pre-update psi / lambda it reads -- behind the next positions' updates, position after position,
+      // until the kernel needs 500 registers.  Making this position's cosine depend on it (times zero: exact) finishes
+      // each reduction before the next un-application starts.
+      if constexpr (POS < 9) c = fma(th[POS + 1], (T)0, c);
+      undo_pos<POS>(a, l, c, cs.y, th[POS]);
       undo_down_to<SET, POS - 1, FROM>(a, l, layer, th);
     }
   }
@@ -104,7 +121,7 @@ struct WideCzAdj : WideCz<T, N> {
   struct Signed {
     T tot = 0;
     T reg[4] = {0, 0, 0, 0};
-    T tile[NB];
+    T tile[NB > 0 ? NB : 1];
   };
   __device__ __forceinline__ void alpha_tile(const C (&a)[R], const C (&l)[R], uint32_t t, Signed& m) const {
     T ck[R];
@@ -184,7 +201,7 @@ struct WideCzAdj : WideCz<T, N> {
 #pragma unroll
     for (int i = 0; i < 10; ++i) th[i] = 0;
     // <Z> read-out: g_eff(k) = sum_w g_w (1 - 2 b_w(k)) = G0 - 2 (lane part + register part + tile part)
-    T g0 = 0, g_lane = 0, g_reg[R], g_tb[NB];
+    T g0 = 0, g_lane = 0, g_reg[R], g_tb[NB > 0 ? NB : 1];
     if (p.measure == 1) {
 #pragma unroll
       for (int w = 0; w < N; ++w) g0 += (T)s_g[w];
@@ -295,13 +312,13 @@ struct WideCzAdj : WideCz<T, N> {
       }
       fl_ex[j] = v;
     }
-    C cs_reg[4], cs_tile[NB];
+    C cs_reg[4], cs_tile[NB > 0 ? NB : 1];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
       cs_reg[rb] = wide_uniform2<T>(this->s_ry[layer_base * N + (N - 1 - G::local_bit(SET, rb == 0 ? 0 : 6 + rb))]);
 #pragma unroll
     for (int i = 0; i < NB; ++i) cs_tile[i] = wide_uniform2<T>(this->s_ry[layer_base * N + (N - 1 - G::tile_bit(SET, i))]);
-    T acc_common = 0, acc_reg[4] = {0, 0, 0, 0}, acc_tile[NB];
+    T acc_common = 0, acc_reg[4] = {0, 0, 0, 0}, acc_tile[NB > 0 ? NB : 1];
 #pragma unroll
     for (int i = 0; i < NB; ++i) acc_tile[i] = 0;
     for (uint32_t t = (uint32_t)this->wave; t < (uint32_t)NT; t += (uint32_t)this->waves) {

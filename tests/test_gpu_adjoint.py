@@ -292,3 +292,30 @@ def test_wide_cz_adjoint_many_samples_and_determinism():
     parts = [run_adjoint(circ, x[i:i + 175], w, g[i:i + 175], "f64") for i in range(0, B, 175)]
     assert torch.allclose(ga, sum(p[0] for p in parts), atol=1e-9)
     assert torch.allclose(gi, torch.cat([p[1] for p in parts]), atol=1e-12)
+
+
+# ---- the register-resident reverse sweep of 10-qubit CZ circuits (qsim_cz10_adjoint.h) -------------------------------
+@pytest.mark.parametrize("L,S,meas,B", [(1, 2, "probs", 5), (9, 2, "probs", 7), (3, 1, "expz", 4), (2, 9, "expz", 3), (1, 3, "probs", 70)])
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-9), ("f32", 2e-4)])
+def test_cz10_adjoint_vs_oracle_autograd(L, S, meas, B, precision, tol):
+    """C3's circuit family (differN_noise: 10 wires, RZ re-upload, SEL(CZ), probabilities) and its <Z> sibling: weights and
+    angle inputs against autograd through the oracle -- 2 to 18 layers, every layer a block start (S = 1), all nine
+    entangler ranges (S = 9), more samples than one wave per workgroup slot (70)."""
+    from oracle import circuits as oc
+    from qiddm_amd.circuit import Circuit, run_adjoint
+    n = 10
+    g_ = torch.Generator().manual_seed(10 * L + S)
+    circ = Circuit(n_qubits=n, encoding="rz", imprimitive="CZ", measure=meas, n_rounds=1, n_blocks=L, sel_layers=S)
+    w = torch.randn(circ.angles_shape, generator=g_, dtype=torch.float64) * 0.6
+    x = torch.rand(B, n, generator=g_, dtype=torch.float64) * 2 - 1
+    g = torch.randn(B, (1 << n) if meas == "probs" else n, generator=g_, dtype=torch.float64)
+    wo, xo = w.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    out = oc.run_circuit(oc.Spec(n=n, encoding="rz", imprimitive="CZ", measure=meas), xo, wo)
+    (out * g).sum().backward()
+    ga, gi = run_adjoint(circ, x.cuda(), w.cuda(), g.cuda(), precision)
+    ga2, gi2 = run_adjoint(circ, x.cuda(), w.cuda(), g.cuda(), precision)
+    assert torch.equal(ga, ga2) and torch.equal(gi, gi2)                     # fixed-order sums
+    sw = max(wo.grad.abs().max().item(), 1e-3)
+    assert (ga.cpu() - wo.grad).abs().max().item() < tol * sw, (ga.cpu() - wo.grad).abs().max().item() / sw
+    sx = max(xo.grad.abs().max().item(), 1e-3)
+    assert (gi.cpu() - xo.grad).abs().max().item() < tol * sx, (gi.cpu() - xo.grad).abs().max().item() / sx
