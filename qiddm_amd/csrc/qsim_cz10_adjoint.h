@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kCz10Waves* kWave, (sizeof(T) == 4 ? 2 : 1)) void c
       {
         typename B::Diag d;
         w.template build_diag<0>(li, bs, (((li - 1) % p.sel_layers) % (N - 1)) + 1, d);
-        w.template undo_diag<0>(a, l, d, 0);
+        w.template undo_diag<0>(a, l, d, 0, W::signed_token(m) + th[0]);
       }
       w.template put_theta<0>(row, 0, th, 0);
       w.template put_signed<0>(row, 16, m);

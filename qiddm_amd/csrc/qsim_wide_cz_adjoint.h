@@ -123,6 +123,12 @@ struct WideCzAdj : WideCz<T, N> {
     T reg[4] = {0, 0, 0, 0};
     T tile[NB > 0 ? NB : 1];
   };
+  __device__ __forceinline__ static T signed_token(const Signed& m) {
+    T v = m.tot + m.reg[0] + m.reg[1] + m.reg[2] + m.reg[3];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) v += m.tile[i];
+    return v;
+  }
   __device__ __forceinline__ void alpha_tile(const C (&a)[R], const C (&l)[R], uint32_t t, Signed& m) const {
     T ck[R];
 #pragma unroll
@@ -141,12 +147,16 @@ struct WideCzAdj : WideCz<T, N> {
 #pragma unroll
     for (int i = 0; i < NB; ++i) m.tile[i] += ((t >> i) & 1u) ? -tot : tot;
   }
+  // `token`: a value computed from the signed sums of alpha_tile; the phase is made to depend on it (times zero: exact)
+  // so that those reductions are finished -- not parked with a copy of psi / lambda -- before the vectors are overwritten
   template <int SET>
-  __device__ __forceinline__ void undo_diag(C (&a)[R], C (&l)[R], const typename B::Diag& d, uint32_t t) const {
+  __device__ __forceinline__ void undo_diag(C (&a)[R], C (&l)[R], const typename B::Diag& d, uint32_t t,
+                                            T token = (T)0) const {
     C tt = C{(T)1, (T)0};
 #pragma unroll
     for (int i = 0; i < NB; ++i) tt = wide_cmul<T>(tt, wide_sel<T>((t >> i) & 1u, d.ut[i]));
     tt = wide_cmul<T>(tt, d.pl);
+    tt.x = fma(token, (T)0, tt.x);
     const uint32_t kt = B::template tile_index_bits<SET>(t);
     const uint32_t x = kt | d.kl;
     const uint32_t y = B::rotl_n(kt, d.range) | d.rl;
@@ -269,7 +279,7 @@ struct WideCzAdj : WideCz<T, N> {
       this->template load_tile<SET>(lam, t, l);
       undo_down_to<SET, 9, 0>(a, l, lcur, th_cur);
       alpha_tile(a, l, t, m);
-      undo_diag<SET>(a, l, d, t);
+      undo_diag<SET>(a, l, d, t, signed_token(m) + th_cur[0]);
       undo_down_to<SET, 9, P>(a, l, lprev, th_prev);
       this->template store_tile<SET>(psi, t, a);
       this->template store_tile<SET>(lam, t, l);
@@ -327,7 +337,7 @@ struct WideCzAdj : WideCz<T, N> {
       this->template load_tile<SET>(lam, t, l);
       undo_down_to<SET, 9, 0>(a, l, lcur, th_cur);
       alpha_tile(a, l, t, m);
-      undo_diag<SET>(a, l, d, t);
+      undo_diag<SET>(a, l, d, t, signed_token(m) + th_cur[0]);
       // layer 0: d/dtheta_w = Re (RY^dagger lambda)[e_w].  The register bits are contracted level by level: after
       // level k, pl[] holds the plain contraction of bits 0..k and ex[j][] the one with bit j's factor pair replaced
       // by its selector pair (-sin, cos) -- five weighted sums for 82 FMAs and no tables
