@@ -47,10 +47,10 @@ Geometry geometry(const qiddm_circuit_t* c, int64_t batch, int32_t pixels, int32
   return g;
 }
 
-template <typename T, int N, bool QUANTUM, int WPB>
+template <typename T, int N, bool QUANTUM, int WPB, bool FOLD>
 int launch_rows(const qiddm_train_args_t* a, const Geometry& g, unsigned char* ws, const qiddm::TrainScalars& d,
                 const qiddm::KScalars& p, size_t smem, int64_t blocks, hipStream_t st) {
-  auto kern = qiddm::train_rows_kernel<T, N, QUANTUM, WPB>;
+  auto kern = qiddm::train_rows_kernel<T, N, QUANTUM, WPB, FOLD>;
   static qiddm_capi::DeviceFlags big_lds_enabled;
   if (smem > 48 * 1024 && !big_lds_enabled.get()) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -127,8 +127,17 @@ int run_step(const qiddm_circuit_t* c, const qiddm_train_args_t* a, const Geomet
                 (long long)g.n_rot_all, smem);
   int64_t k_blocks = (groups + WPB - 1) / WPB;
   if (k_blocks > kMaxRowBlocks) k_blocks = kMaxRowBlocks;
-  const int rc = q ? launch_rows<T, N, true, WPB>(a, g, ws, d, p, smem, k_blocks, st)
-                   : launch_rows<T, N, false, WPB>(a, g, ws, d, p, smem, k_blocks, st);
+  int rc;
+  if (!q) {
+    rc = launch_rows<T, N, false, WPB, false>(a, g, ws, d, p, smem, k_blocks, st);
+  } else if (d.fold) {
+    if constexpr (N >= 2 && N <= qiddm::kFoldedAdjointMaxQubits)
+      rc = launch_rows<T, N, true, WPB, true>(a, g, ws, d, p, smem, k_blocks, st);
+    else
+      rc = fail(QIDDM_ERR_UNSUPPORTED, "folded training sweep is not instantiated for n_qubits=%d", N);
+  } else {
+    rc = launch_rows<T, N, true, WPB, false>(a, g, ws, d, p, smem, k_blocks, st);
+  }
   if (rc != QIDDM_OK) return rc;
 
   // ---- 2. weight-gradient partials ----------------------------------------------------------------------

@@ -129,7 +129,11 @@ struct AdjointEngine {
                                                 T (&gth)[16]) const {
     if constexpr (W < N) {
       constexpr int Q = N - 1 - W;
-      const T c = f.ry[W].x, s = f.ry[W].y;
+      T c = f.ry[W].x;
+      const T s = f.ry[W].y;
+      // ordering token (see qsim_wide_cz_adjoint.h: undo_down_to): the previous wire's reduction is finished before this
+      // wire's un-application overwrites the values it reads, instead of being parked with a copy of them
+      if constexpr (W > 0) c = fma(gth[W - 1], (T)0, c);
       if constexpr (E::template kind_of<W>() == E::kReg) {
         gth[W] = ry_back_pairs<(1 << (Q >= LB ? Q - LB : 0))>(psi, lam, c, s);
       } else if constexpr (E::template kind_of<W>() == E::kSwap) {

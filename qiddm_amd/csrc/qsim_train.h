@@ -176,13 +176,19 @@ __host__ __device__ inline size_t train_lds_bytes(int64_t n_rot_all, int n_round
   size_t b = Smem<T, N>::bytes(n_rot_all, cnot, waves);
   if (quantum) b += (size_t)n_rot_all * kLdsGateReals * sizeof(T) + (size_t)waves * n_rot_all * 8 * sizeof(T);
   b += (size_t)waves * Layout<N>::SPW * n_rounds * N * sizeof(T);
+  if (quantum) {  // G, c, s as doubles (8-byte aligned) + one N-vector per sample in flight to hand d loss / d <Z> around
+    b = (b + 7) & ~(size_t)7;
+    b += (size_t)(N + 2) * N * sizeof(double) + (size_t)waves * Layout<N>::SPW * N * sizeof(T);
+  }
   return b;
 }
 
 // ---------------------------------------------------------------------------
 // 1b. the circuit, forward and (QUANTUM) reverse, one wavefront per row
 // ---------------------------------------------------------------------------
-template <typename T, int N, bool QUANTUM, int WPB>
+// FOLD (compile time, = d.fold): the folded forward / reverse sweep of CZ circuits; keeping the general gate-by-gate
+// path out of that instantiation is worth registers (n = 8: 256 VGPRs + 65 spills with both paths compiled in)
+template <typename T, int N, bool QUANTUM, int WPB, bool FOLD>
 __global__ __launch_bounds__(WPB* kWave, QUANTUM ? QIDDM_TRAIN_OCC : 1) void train_rows_kernel(
     const double* __restrict__ proj, const double* __restrict__ bd, const double* __restrict__ angles,
     double* __restrict__ ev_out, double* __restrict__ gxr_out, T* __restrict__ k_partials, int64_t batch,
@@ -206,20 +212,27 @@ __global__ __launch_bounds__(WPB* kWave, QUANTUM ? QIDDM_TRAIN_OCC : 1) void tra
     cur = reinterpret_cast<unsigned char*>(kall + (size_t)WPB * n_rot_all * 8);
   }
   T* hist_all = reinterpret_cast<T*>(cur);
-  const bool folded = QUANTUM && d.fold != 0 && N >= 2 && N <= kFoldedAdjointMaxQubits;
+  cur += (size_t)WPB * SPW * p.n_rounds * N * sizeof(T);
+  cur = smem_raw + (((size_t)(cur - smem_raw) + 7) & ~(size_t)7);
+  double* s_gram = reinterpret_cast<double*>(cur);  // [N][N] G (row j' at s_gram[j' * N + j]), then c[N], s[N]
+  T* s_gw_all = reinterpret_cast<T*>(s_gram + (N + 2) * N);
+  constexpr bool folded = QUANTUM && FOLD && N >= 2 && N <= kFoldedAdjointMaxQubits;
   const int layers = p.n_blocks * p.sel_layers;  // per round
   using AE = AdjointEngine<T, N>;
   const int acc_len = folded ? p.n_rounds * layers * 2 * AE::kFoldSlots : n_rot_all * 8;
-  if (folded)
+  if constexpr (folded)
     adj.fwd.fill_folded_from_angles(angles, p.n_rounds * layers, layers);
   else
     adj.fwd.fill_gates_from_angles(angles, n_rot_all);
   adj.fwd.fill_rings(use_cnot);
-  if constexpr (QUANTUM)
+  if constexpr (QUANTUM) {
     for (int i = threadIdx.x; i < WPB * acc_len; i += blockDim.x) kall[i] = 0;
+    const double* __restrict__ g0 = proj + batch * (d.T + 1) * (2 * N) + N;  // unit u's W_up half at g0[u * 2N + j]
+    for (int i = threadIdx.x; i < (N + 2) * N; i += blockDim.x) s_gram[i] = g0[(size_t)(i / N) * (2 * N) + (i % N)];
+  }
   __syncthreads();
   if constexpr (QUANTUM) {
-    if (!folded) {
+    if constexpr (!folded) {
       // U^dagger images from the forward ones: (u00*, u10*; u01*, u11*)
       for (int g = threadIdx.x; g < n_rot_all; g += blockDim.x) {
         const T* f = adj.fwd.s_gates_w + (size_t)g * kLdsGateReals;
@@ -237,9 +250,7 @@ __global__ __launch_bounds__(WPB* kWave, QUANTUM ? QIDDM_TRAIN_OCC : 1) void tra
   const int swave = adj.fwd.llane >> LB;
   T* kacc_wave = kall + (size_t)wave * acc_len;
   T* hist = hist_all + (size_t)(wave * SPW + swave) * p.n_rounds * N;
-  const double* __restrict__ gram = proj + batch * (d.T + 1) * (2 * N) + N;  // row j' of G at gram[j'*2N + j]
-  const double* __restrict__ cvec = gram + (size_t)N * (2 * N);
-  const double* __restrict__ svec = cvec + 2 * N;
+  T* s_gw = s_gw_all + (size_t)(wave * SPW + swave) * N;
 
   const int64_t groups = (d.rows + SPW - 1) / SPW;
   for (int64_t grp = (int64_t)blockIdx.x * WPB + wave; grp < groups; grp += (int64_t)gridDim.x * WPB) {
@@ -264,7 +275,7 @@ __global__ __launch_bounds__(WPB* kWave, QUANTUM ? QIDDM_TRAIN_OCC : 1) void tra
         for (int j = 0; j < N; ++j) hist[round * N + j] = xs[j];
       }
       adj.fwd.s_gates = fwd_base + (size_t)round * round_gate_stride;
-      if (folded)
+      if constexpr (folded)
         adj.forward_round_folded(p, NoSrc{}, xs, psi, dx, cs, sn, amp_inv, layers);
       else
         adj.forward_round(p, NoSrc{}, xs, psi, dx, cs, sn, amp_inv);
@@ -282,14 +293,22 @@ __global__ __launch_bounds__(WPB* kWave, QUANTUM ? QIDDM_TRAIN_OCC : 1) void tra
     }
     if constexpr (QUANTUM) {
       // ---- d loss / d <Z_j> from the projections ---------------------------------------------------
+      // lane j of the sample takes component j (one column of G from LDS, 2n + 1 flops), the n results go round
+      // through LDS: the whole matrix in scalar registers cost ~1000 v_readlane of spilled SGPRs per row
       T gw[N];
+      {
+        const int j = sub < N ? sub : 0;
+        double ge = s_gram[N * N + j];
 #pragma unroll
-      for (int j = 0; j < N; ++j) {
-        double ge = cvec[j];
+        for (int jp = 0; jp < N; ++jp) ge = fma(s_gram[jp * N + j], (double)result[jp], ge);
+        const double g =
+            d.goal == 0 ? ge - pcl[N + j] : 0.1 * ge - 0.05 * s_gram[(N + 1) * N + j] - pn[N + j] + pcl[N + j];
+        if (sub < N) s_gw[sub] = valid ? (T)(d.grad_scale * g) : (T)0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // LDS hand-over inside the wavefront
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int jp = 0; jp < N; ++jp) ge = fma(gram[(size_t)jp * (2 * N) + j], (double)result[jp], ge);
-        const double g = d.goal == 0 ? ge - pcl[N + j] : 0.1 * ge - 0.05 * svec[j] - pn[N + j] + pcl[N + j];
-        gw[j] = valid ? (T)(d.grad_scale * g) : (T)0;
+        for (int jj = 0; jj < N; ++jj) gw[jj] = s_gw[jj];
       }
       // ---- reverse sweep, last round first; earlier rounds are re-run forward from their recorded inputs ----
       for (int round = p.n_rounds - 1; round >= 0; --round) {
@@ -299,7 +318,7 @@ __global__ __launch_bounds__(WPB* kWave, QUANTUM ? QIDDM_TRAIN_OCC : 1) void tra
         if (round != p.n_rounds - 1) {
 #pragma unroll
           for (int j = 0; j < N; ++j) xs[j] = hist[round * N + j];
-          if (folded)
+          if constexpr (folded)
             adj.forward_round_folded(p, NoSrc{}, xs, psi, dx, cs, sn, amp_inv, layers);
           else
             adj.forward_round(p, NoSrc{}, xs, psi, dx, cs, sn, amp_inv);
@@ -307,7 +326,7 @@ __global__ __launch_bounds__(WPB* kWave, QUANTUM ? QIDDM_TRAIN_OCC : 1) void tra
         C lam[R];
         adj.seed_expz(gw, psi, lam);
         T gx[N];
-        if (folded)
+        if constexpr (folded)
           adj.reverse_round_folded(p, psi, lam, cs, sn, gx, adj.kacc);
         else
           adj.reverse_round(p, psi, lam, dx, cs, sn, gx);

@@ -43,6 +43,8 @@ def test_introspection_calls_need_no_gpu(hip_lib):
         n = circ.n_qubits
         lb = min(n, 6)
         folded = 0 if n > 10 else (rot // n) * 2 * (n + 2 ** lb + 2 ** (n - lb))   # per-layer tables for CZ circuits
+        if n == 10 and circ.imprimitive == "CZ" and circ.encoding in ("none", "rz"):
+            folded += 2 * rot * 2                     # + the per-wire tables of the n = 10 reverse sweep (2n entries a layer)
         assert hip_lib.qiddm_gate_table_elems(ctypes.byref(cs)) == rot * 56 + folded
     cs = cases[1][0].c_struct("f32")
     assert hip_lib.qiddm_num_shift_replicas(ctypes.byref(cs), 0) == 6 * 192

@@ -12,7 +12,8 @@ net = nn.QNN_noise(784, 8, 14, detach_quantum=(mode == "detached"))
 if mode == "adjoint":
     net.qnode.diff_method = "adjoint"
 diff = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (28, 28), torch.nn.MSELoss()).to("cuda", dtype=torch.double).train()
-x = torch.rand(256, 784, dtype=torch.double, device="cuda")
+B = int(os.environ.get("QIDDM_TRAIN_BATCH", "256"))
+x = torch.rand(B, 784, dtype=torch.double, device="cuda")
 from qiddm_amd.optim import FusedAdam
 step = GraphedTrainStep(diff, FusedAdam(diff.parameters(), lr=1e-3), x, T=10, noise=os.environ.get("QIDDM_TRAIN_NOISE", "fused"))
 for _ in range(5):
@@ -23,4 +24,4 @@ for _ in range(200):
     step(x)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 200
-print(f"{mode}: {dt*1e6:.1f} us/step, {2560/dt/1e6:.2f} M img/s")
+print(f"{mode}: batch {B}: {dt*1e6:.1f} us/step, {B*10/dt/1e6:.2f} M img/s")
