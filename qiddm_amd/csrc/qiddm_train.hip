@@ -109,7 +109,7 @@ int run_step(const qiddm_circuit_t* c, const qiddm_train_args_t* a, const Geomet
   // ---- 1a. projections (only the reverse sweep and linear_down consume them) ---------------------------------
   {
     const int64_t units = a->batch * ((a->tau + qiddm::kProjLevels) / qiddm::kProjLevels) + (q ? N + 2 : 0);
-    hipLaunchKernelGGL(qiddm::train_project_kernel<N>, dim3((unsigned)((units + 3) / 4)), dim3(4 * qiddm::kWave), 0,
+    hipLaunchKernelGGL(qiddm::train_project_kernel<N>, dim3((unsigned)units), dim3(qiddm::kProjWaves * qiddm::kWave), 0,
                        st, a->x, a->noise, a->rng_state, a->schedule, a->w_down, a->w_up, a->b_up,
                        reinterpret_cast<double*>(ws + g.off_proj), a->batch, d);
     e = hipGetLastError();

@@ -109,12 +109,15 @@ struct AdjointEngine {
 
   template <int J>
   __device__ __forceinline__ T ry_back_pairs(C (&psi)[R], C (&lam)[R], T c, T s) const {
-    T g = 0;
+    // (re, im) products accumulated as a pair: the operands are register pairs already, so these are plain packed
+    // fmas -- written out as a scalar sum the SLP vectoriser packs them too, but with ~14 moves per wire to pair them up
+    C g2 = C{(T)0, (T)0};
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if ((r & J) == 0) {
         const C p0 = psi[r], p1 = psi[r | J], l0 = lam[r], l1 = lam[r | J];
-        g += (l1.x * p0.x + l1.y * p0.y) - (l0.x * p1.x + l0.y * p1.y);
+        g2 = __builtin_elementwise_fma(l1, p0, g2);
+        g2 = __builtin_elementwise_fma(-l0, p1, g2);
         // RY^dagger = [[c, s], [-s, c]]
         psi[r] = __builtin_elementwise_fma(bcast<T>(s), p1, bcast<T>(c) * p0);
         psi[r | J] = __builtin_elementwise_fma(bcast<T>(-s), p0, bcast<T>(c) * p1);
@@ -122,7 +125,7 @@ struct AdjointEngine {
         lam[r | J] = __builtin_elementwise_fma(bcast<T>(-s), l0, bcast<T>(c) * l1);
       }
     }
-    return g;
+    return g2.x + g2.y;
   }
   template <int W>
   __device__ __forceinline__ void ry_back_wires(C (&psi)[R], C (&lam)[R], const typename E::FoldedLayer& f,
@@ -147,15 +150,16 @@ struct AdjointEngine {
       } else {
         const bool hi = (fwd.llane >> Q) & 1;
         const T sg = hi ? s : -s;  // the forward coefficient of the partner in this lane's row
-        T acc = 0;
+        C acc2 = C{(T)0, (T)0};
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const C pp = xlane2<(1 << Q), T>(psi[r], fwd.lane);
           const C lp = xlane2<(1 << Q), T>(lam[r], fwd.lane);
-          acc += lam[r].x * pp.x + lam[r].y * pp.y;  // Re(conj(lambda_own) psi_partner)
+          acc2 = __builtin_elementwise_fma(lam[r], pp, acc2);  // Re(conj(lambda_own) psi_partner) = .x + .y
           psi[r] = __builtin_elementwise_fma(bcast<T>(-sg), pp, bcast<T>(c) * psi[r]);
           lam[r] = __builtin_elementwise_fma(bcast<T>(-sg), lp, bcast<T>(c) * lam[r]);
         }
+        const T acc = acc2.x + acc2.y;
         gth[W] = hi ? acc : -acc;
       }
       ry_back_wires<W + 1>(psi, lam, f, gth);

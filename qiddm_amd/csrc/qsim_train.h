@@ -84,7 +84,7 @@ __device__ __forceinline__ double residual(int goal, double out, double noisy, d
 
 // ---------------------------------------------------------------------------
 // 1a. projections.  Every place the (rows, P) tensors meet a weight matrix is a dot product of a blended row
-// with a column of W_down or W_up, so they are all taken here, once, one wavefront per (sample b, level t):
+// with a column of W_down or W_up, so they are all taken here, once, one workgroup per (sample b, four levels t):
 //     proj[(b*(T+1)+t)*2n + j]     = sum_p whole[b,t,p] W_down[j,p]            j < n
 //     proj[(b*(T+1)+t)*2n + n + j] = sum_p whole[b,t,p] W_up[p,j]
 // and n+2 more units with W_up[:,j'], b_up and 1 in place of `whole` (G = W_up^T W_up, c = W_up^T b_up,
@@ -93,22 +93,61 @@ __device__ __forceinline__ double residual(int goal, double out, double noisy, d
 //                      = grad_scale * (0.1 (G ev + c)_j - 0.05 s_j - NU_j + CU_j)            goal "noise"
 // (NU / CU = the W_up projections of the noisy / clean row).
 // ---------------------------------------------------------------------------
-constexpr int kProjLevels = 4;  // noise levels per wavefront: each weight fetched once serves this many rows
+constexpr int kProjLevels = 4;  // noise levels per workgroup: each weight fetched once serves this many rows
+constexpr int kProjWaves = 4;   // wavefronts per unit, each takes every fourth 64-pixel strip
+
+// a + b summed across the lane pair that differs in bit 4 (MASK 16) / 5 (MASK 32), for two values at once: the lane
+// with the bit clear gets  a(own) + a(partner), the lane with the bit set  b(own) + b(partner).  One permlane swap per
+// dword exchanges a's set-bit half with b's clear-bit half, after which both sums are simply a + b.
+template <int MASK>
+__device__ __forceinline__ double swap_pair_sum(double a, double b) {
+  uint32_t alo = (uint32_t)__double2loint(a), ahi = (uint32_t)__double2hiint(a);
+  uint32_t blo = (uint32_t)__double2loint(b), bhi = (uint32_t)__double2hiint(b);
+  if constexpr (MASK == 32) {
+    const auto lo = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    alo = lo[0], blo = lo[1], ahi = hi[0], bhi = hi[1];
+  } else {
+    static_assert(MASK == 16, "swap steps are the two row-crossing lane bits");
+    const auto lo = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    alo = lo[0], blo = lo[1], ahi = hi[0], bhi = hi[1];
+  }
+  return __hiloint2double((int)ahi, (int)alo) + __hiloint2double((int)bhi, (int)blo);
+}
+
+// Sums of 64 per-lane values over the wavefront by halving: after the step on lane bit k only the half of the values
+// whose index has bit k equal to the lane's stays in the lane, so 63 exchanges do what 64 butterflies (384) would.
+// The lane with LOGICAL number L returns the total of v[L].  Destroys v.
+__device__ __forceinline__ double wave_transpose_sum64(double (&v)[64], int lane, int llane) {
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v[i] = swap_pair_sum<32>(v[i], v[32 + i]);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = swap_pair_sum<16>(v[i], v[16 + i]);
+  const bool b3 = llane & 8, b2 = llane & 4, b1 = llane & 2, b0 = llane & 1;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (b3 ? v[8 + i] : v[i]) + xlane<8>(b3 ? v[i] : v[8 + i], lane);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = (b2 ? v[4 + i] : v[i]) + xlane<4>(b2 ? v[i] : v[4 + i], lane);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) v[i] = (b1 ? v[2 + i] : v[i]) + xlane<2>(b1 ? v[i] : v[2 + i], lane);
+  return (b0 ? v[1] : v[0]) + xlane<1>(b0 ? v[0] : v[1], lane);
+}
 
 template <int N>
-__global__ __launch_bounds__(4 * kWave) void train_project_kernel(
+__global__ __launch_bounds__(kProjWaves* kWave) void train_project_kernel(
     const double* __restrict__ x, float* __restrict__ noise, const uint64_t* __restrict__ rng,
     const float* __restrict__ sched, const double* __restrict__ wd, const double* __restrict__ wu,
     const double* __restrict__ bu, double* __restrict__ proj, int64_t batch, const TrainScalars d) {
   constexpr int LG = kProjLevels;
+  __shared__ double s_part[kProjWaves][LG * 2 * N];
   const int P = d.pixels;
-  const int lane = threadIdx.x & (kWave - 1);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
   const int groups_per_sample = (d.T + 1 + LG - 1) / LG;
-  const int64_t unit = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t unit = blockIdx.x;  // grid = n_blend (+ N + 2 when the quantum weights train)
   const int64_t n_blend = batch * groups_per_sample;
   // (as written, finding F1, nothing downstream reads the W_up projections: only W_down x is taken)
   const bool quantum = d.train_quantum != 0;
-  if (unit >= n_blend + (quantum ? N + 2 : 0)) return;
   const int kind = unit < n_blend ? 0 : (int)(unit - n_blend) + 1;  // 0 blend, 1..N W_up column, N+1 b_up, N+2 ones
   const int64_t b = kind == 0 ? unit / groups_per_sample : 0;
   const int t0 = kind == 0 ? (int)(unit - b * groups_per_sample) * LG : 0;
@@ -120,9 +159,9 @@ __global__ __launch_bounds__(4 * kWave) void train_project_kernel(
   for (int l = 0; l < LG; ++l)
 #pragma unroll
     for (int j = 0; j < 2 * N; ++j) acc[l][j] = 0.0;
-  // one wavefront per SIMD at the benchmark shapes: keep several iterations' loads in flight
-#pragma unroll 4
-  for (int pix = lane; pix < P; pix += kWave) {
+  // 3120 wavefronts at the benchmark shapes (three per SIMD), three or four strips each
+#pragma unroll 2
+  for (int pix = wave * kWave + lane; pix < P; pix += kProjWaves * kWave) {
     double wdv[N], wuv[N];
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -154,18 +193,37 @@ __global__ __launch_bounds__(4 * kWave) void train_project_kernel(
       for (int j = 0; j < N; ++j) acc[0][N + j] = fma(v, wuv[j], acc[0][N + j]);
     }
   }
+  // this wavefront's strip sums -> s_part[wave][l * 2N + j]
+  if constexpr (LG == 4 && N <= 8) {  // value (l, j) at index 16 l + j
+    const int llane = logical_lane(lane);
+    double v[64];
 #pragma unroll
-  for (int l = 0; l < LG; ++l) {
-    double mine = 0.0;
+    for (int i = 0; i < 64; ++i) v[i] = (i & 15) < 2 * N ? acc[i >> 4][(i & 15) < 2 * N ? (i & 15) : 0] : 0.0;
+    const double tot = wave_transpose_sum64(v, lane, llane);
+    if ((llane & 15) < 2 * N) s_part[wave][(llane >> 4) * 2 * N + (llane & 15)] = tot;
+  } else {
 #pragma unroll
-    for (int j = 0; j < 2 * N; ++j) {
-      const double tot = group_sum<double, 6>(acc[l][j], lane);
-      mine = fma((double)(lane == j ? 1 : 0), tot, mine);
+    for (int l = 0; l < LG; ++l) {
+      double mine = 0.0;
+#pragma unroll
+      for (int j = 0; j < 2 * N; ++j) {
+        const double tot = group_sum<double, 6>(acc[l][j], lane);
+        mine = fma((double)(lane == j ? 1 : 0), tot, mine);
+      }
+      if (lane < 2 * N) s_part[wave][l * 2 * N + lane] = mine;
     }
+  }
+  __syncthreads();
+  // the strips in a fixed order
+  for (int i = threadIdx.x; i < LG * 2 * N; i += blockDim.x) {
+    double tot = s_part[0][i];
+#pragma unroll
+    for (int wv = 1; wv < kProjWaves; ++wv) tot += s_part[wv][i];
+    const int l = i / (2 * N), j = i - l * (2 * N);
     if (kind == 0) {
-      if (t0 + l <= d.T && lane < 2 * N) proj[(b * (d.T + 1) + t0 + l) * (2 * N) + lane] = mine;
-    } else if (l == 0 && lane < 2 * N) {
-      proj[(batch * (d.T + 1) + (kind - 1)) * (2 * N) + lane] = mine;
+      if (t0 + l <= d.T) proj[(b * (d.T + 1) + t0 + l) * (2 * N) + j] = tot;
+    } else if (l == 0) {
+      proj[(batch * (d.T + 1) + (kind - 1)) * (2 * N) + j] = tot;
     }
   }
 }
