@@ -48,22 +48,20 @@ struct WideCzAdj : WideCz<T, N> {
   __device__ __forceinline__ void undo_pairs(C (&a)[R], C (&l)[R], T c, T s, T& th) const {
     // two FMA chains (no product temporaries: written as sums of products the scheduler hoists every multiply and the
     // kernel needs 500 registers), each pair un-applied right after its contribution
-    T t0 = 0, t1 = 0;
+    C t2 = C{(T)0, (T)0};  // (re, im) products as one packed chain: the operands are register pairs already
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if ((r & J) == 0) {
         const C a0 = a[r], a1 = a[r | J], l0 = l[r], l1 = l[r | J];
-        t0 = fma(l1.x, a0.x, t0);
-        t1 = fma(l1.y, a0.y, t1);
-        t0 = fma(-l0.x, a1.x, t0);
-        t1 = fma(-l0.y, a1.y, t1);
+        t2 = __builtin_elementwise_fma(l1, a0, t2);
+        t2 = __builtin_elementwise_fma(-l0, a1, t2);
         a[r] = __builtin_elementwise_fma(bcast<T>(s), a1, bcast<T>(c) * a0);
         a[r | J] = __builtin_elementwise_fma(bcast<T>(-s), a0, bcast<T>(c) * a1);
         l[r] = __builtin_elementwise_fma(bcast<T>(s), l1, bcast<T>(c) * l0);
         l[r | J] = __builtin_elementwise_fma(bcast<T>(-s), l0, bcast<T>(c) * l1);
       }
     }
-    th += t0 + t1;
+    th += t2.x + t2.y;
   }
   template <int POS>
   __device__ __forceinline__ void undo_pos(C (&a)[R], C (&l)[R], T c, T s, T& th) const {
@@ -73,16 +71,16 @@ struct WideCzAdj : WideCz<T, N> {
       constexpr int LBIT = POS - 1;
       const bool hi = (this->llane >> LBIT) & 1;
       const T sg = hi ? -s : s;   // RY^dagger = [[c, s], [-s, c]]
-      T tc = 0;
+      C tc2 = C{(T)0, (T)0};
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const C pa = xlane2<(1 << LBIT), T>(a[r], this->lane);
         const C pl = xlane2<(1 << LBIT), T>(l[r], this->lane);
-        tc = fma(l[r].x, pa.x, tc);   // own lambda with the partner's psi
-        tc = fma(l[r].y, pa.y, tc);
+        tc2 = __builtin_elementwise_fma(l[r], pa, tc2);   // own lambda with the partner's psi
         a[r] = __builtin_elementwise_fma(bcast<T>(sg), pa, bcast<T>(c) * a[r]);
         l[r] = __builtin_elementwise_fma(bcast<T>(sg), pl, bcast<T>(c) * l[r]);
       }
+      const T tc = tc2.x + tc2.y;
       th += hi ? tc : -tc;
     } else if constexpr (POS <= 6) {
       constexpr int LBIT = POS - 1;
