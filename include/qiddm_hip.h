@@ -428,6 +428,16 @@ int qiddm_qconv_train_backward(int32_t n_qubits, const double *x, int64_t batch,
                                int64_t height, int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
                                const double *grad_y, int64_t out_channels, const float *rows, int32_t row_channels,
                                float *grad_features_t, float *h_partials, double *grad_x, void *stream);
+/* the same with x as a float32 copy of the activations (every patch element is converted to float32 before the products
+ * anyway, so the results are identical; half the bytes and registers of the gather).  Taken where the matrix-core kernel
+ * runs the layer -- qiddm_qconv_train_x32_ok() returns 1 -- and QIDDM_ERR_UNSUPPORTED otherwise.                  */
+int32_t qiddm_qconv_train_x32_ok(int64_t batch, int64_t in_channels, int64_t height, int64_t width, int64_t kh,
+                                 int64_t kw, int64_t pad_h, int64_t pad_w, int64_t out_channels, int32_t row_channels);
+int qiddm_qconv_train_backward_x32(int32_t n_qubits, const float *x, int64_t batch, int64_t in_channels,
+                                   int64_t height, int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
+                                   const double *grad_y, int64_t out_channels, const float *rows,
+                                   int32_t row_channels, float *grad_features_t, float *h_partials, double *grad_x,
+                                   void *stream);
 int64_t qiddm_matrix_adjoint_partials(int64_t count);
 int64_t qiddm_matrix_adjoint_workspace_bytes(const qiddm_circuit_t *circ, int64_t count);
 int qiddm_matrix_adjoint(const qiddm_circuit_t *circ, const double *psi0, const double *lambda, int64_t count,

@@ -62,6 +62,8 @@ EXPORTS = (
     "qiddm_qconv_train_vectors",
     "qiddm_qconv_train_partials",
     "qiddm_qconv_train_backward",
+    "qiddm_qconv_train_x32_ok",
+    "qiddm_qconv_train_backward_x32",
     "qiddm_matrix_adjoint_partials",
     "qiddm_matrix_adjoint_workspace_bytes",
     "qiddm_matrix_adjoint",
@@ -167,6 +169,10 @@ def _declare(lib):
     lib.qiddm_qconv_train_backward.restype = ctypes.c_int
     lib.qiddm_qconv_train_backward.argtypes = [ctypes.c_int32, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, vp,
                                                ctypes.c_int32, vp, vp, vp, vp]
+    lib.qiddm_qconv_train_x32_ok.restype = ctypes.c_int32
+    lib.qiddm_qconv_train_x32_ok.argtypes = [i64, i64, i64, i64, i64, i64, i64, i64, i64, ctypes.c_int32]
+    lib.qiddm_qconv_train_backward_x32.restype = ctypes.c_int
+    lib.qiddm_qconv_train_backward_x32.argtypes = lib.qiddm_qconv_train_backward.argtypes
     lib.qiddm_matrix_adjoint_partials.restype = ctypes.c_int64
     lib.qiddm_matrix_adjoint_partials.argtypes = [i64]
     lib.qiddm_matrix_adjoint_workspace_bytes.restype = ctypes.c_int64

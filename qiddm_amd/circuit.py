@@ -11,6 +11,7 @@ be built, otherwise the call raises.
 from __future__ import annotations
 
 import ctypes
+import os
 from dataclasses import dataclass, replace
 
 import torch
@@ -641,6 +642,10 @@ def _angle_grads_from_h(hpart, n_part, angles, n_qubits, f, c_out, co, device):
     return ga.reshape(angles.shape)
 
 
+# QIDDM_QCONV_X32=1: hand the thin-product backward a float32 copy of the activations (qiddm_qconv_train_backward_x32).
+# Measured at the unet_simple layer shapes (tools/stamp_qconv_train.py) the copy pass costs what the lighter gather gains
+# (1.35 vs 1.26 ms, 0.95 vs 0.93 ms, 0.34 vs 0.36 ms per layer backward), so float64 activations go in as they are
+_QCONV_X32 = os.environ.get("QIDDM_QCONV_X32", "0") == "1"
 _GEMM_CHUNK_BYTES = 256 << 20      # patch matrix of one batch chunk on the "gemm" route
 
 
@@ -714,15 +719,18 @@ class _QConvUnitaryFunction(torch.autograd.Function):
         lib = _capi.lib()
         st = _stream_ptr(device)
         rt = _unitary_rows(u, n_qubits, f, c_out, co, device)
-        xx = _as_f64(x, device).contiguous()
+        # the matrix-core kernel converts every patch element to float32 anyway: hand it a float32 copy (one elementwise
+        # pass; its gather then holds half the bytes in flight)
+        x32 = _QCONV_X32 and bool(lib.qiddm_qconv_train_x32_ok(b, c, h, w, kh, kw, ph, pw, c_out, co))
+        xx = x.detach().to(device=device, dtype=torch.float32).contiguous() if x32 else _as_f64(x, device).contiguous()
         gy = _as_f64(grad_y, device).contiguous()
         n_part = lib.qiddm_qconv_train_partials(b, ho, wo, f)
         gfeat_t = torch.empty(f, b * ho * wo, dtype=torch.float32, device=device)
         hpart = torch.empty(n_part, 2 * co, f + 1, dtype=torch.float32, device=device)
         gx = torch.empty(b, c, h, w, dtype=torch.float64, device=device) if need_gx else None
-        _capi.check(lib.qiddm_qconv_train_backward(n_qubits, xx.data_ptr(), b, c, h, w, kh, kw, ph, pw, gy.data_ptr(),
-                                                   c_out, rt.data_ptr(), co, gfeat_t.data_ptr(), hpart.data_ptr(),
-                                                   0 if gx is None else gx.data_ptr(), st))
+        entry = lib.qiddm_qconv_train_backward_x32 if x32 else lib.qiddm_qconv_train_backward
+        _capi.check(entry(n_qubits, xx.data_ptr(), b, c, h, w, kh, kw, ph, pw, gy.data_ptr(), c_out, rt.data_ptr(), co,
+                          gfeat_t.data_ptr(), hpart.data_ptr(), 0 if gx is None else gx.data_ptr(), st))
         ga = _angle_grads_from_h(hpart, n_part, angles, n_qubits, f, c_out, co, device)
         return (None if gx is None else gx.to(x.dtype)), ga.to(angles.dtype), None, None, None, None
 

@@ -249,10 +249,105 @@ int64_t qiddm_qconv_train_partials(int64_t batch, int64_t height_out, int64_t wi
   return train_grid(batch * height_out * width_out, features);
 }
 
+extern "C++" {
+namespace {
+// the matrix-core variant of the thin-product backward for this layer (nullptr: the VALU kernel keeps it)
+struct TmChoice {
+  const void* kern = nullptr;
+  size_t smem = 0;
+};
+TmChoice train_mfma_choice(int64_t f, int32_t row_channels, bool fits32, bool x32, int64_t kh, int64_t kw, int64_t c_in) {
+  // from 32 patch features on and whenever its LDS tiles fit; the VALU kernel keeps the narrowest layers (9 / 16
+  // features: the whole backward of the layer measured 0.37 / 0.55 ms against 0.53 / 0.67 on the MFMA kernel at
+  // 2560 x 28 x 28 pixels, tools/stamp_qconv_train.py; from 32 features on the MFMA kernel wins) and the widest.
+  // QIDDM_QCONV_VALU=1 / QIDDM_QCONV_MFMA=1: kernel experiments (A/B on the same box)
+  static const bool env_mfma = std::getenv("QIDDM_QCONV_MFMA") != nullptr;
+  static const bool env_valu = std::getenv("QIDDM_QCONV_VALU") != nullptr;
+  TmChoice ch;
+  if (env_valu || !fits32 || (f < 32 && !env_mfma)) return ch;
+  const int jbm = (int)((qiddm::tm_fcols((int)f) / 16 + qiddm::kTmWaves - 1) / qiddm::kTmWaves);
+#define QIDDM_TM_CASE(CO, J)                                                                                       \
+  if (!ch.kern && row_channels == CO && jbm <= J && qiddm::tm_lds_bytes<CO>((int)f) <= kMaxLds) {                   \
+    ch.smem = qiddm::tm_lds_bytes<CO>((int)f);                                                                     \
+    ch.kern = x32 ? reinterpret_cast<const void*>(qiddm::qconv_train_backward_mfma_kernel<CO, J, float>)           \
+                  : reinterpret_cast<const void*>(qiddm::qconv_train_backward_mfma_kernel<CO, J, double>);         \
+  }
+  // the layer shapes of unet_simple with kernel extent and channel count compiled in (no control flow in the gather)
+  static const bool env_generic = std::getenv("QIDDM_QCONV_GENERIC") != nullptr;
+#define QIDDM_TM_SCASE(CO, J, SK, SC)                                                                              \
+  if (!ch.kern && !env_generic && row_channels == CO && jbm <= J && kh == SK && kw == SK && c_in == SC &&          \
+      qiddm::tm_lds_bytes<CO>((int)f) <= kMaxLds) {                                                                \
+    ch.smem = qiddm::tm_lds_bytes<CO>((int)f);                                                                     \
+    ch.kern = x32 ? reinterpret_cast<const void*>(qiddm::qconv_train_backward_mfma_kernel<CO, J, float, SK, SC>)   \
+                  : reinterpret_cast<const void*>(qiddm::qconv_train_backward_mfma_kernel<CO, J, double, SK, SC>); \
+  }
+  QIDDM_TM_SCASE(8, 4, 3, 16)
+  QIDDM_TM_SCASE(16, 2, 3, 8)
+  QIDDM_TM_SCASE(16, 2, 1, 32)
+  QIDDM_TM_SCASE(16, 8, 3, 32)
+  QIDDM_TM_SCASE(32, 4, 3, 16)
+#undef QIDDM_TM_SCASE
+  QIDDM_TM_CASE(8, 2)
+  QIDDM_TM_CASE(8, 4)
+  QIDDM_TM_CASE(8, 8)
+  QIDDM_TM_CASE(16, 2)
+  QIDDM_TM_CASE(16, 4)
+  QIDDM_TM_CASE(16, 8)
+  QIDDM_TM_CASE(32, 2)
+  QIDDM_TM_CASE(32, 4)
+  QIDDM_TM_CASE(32, 8)
+#undef QIDDM_TM_CASE
+  return ch;
+}
+bool train_fits32(int64_t batch, int64_t in_channels, int64_t height, int64_t width, int64_t out_channels, int64_t ho,
+                  int64_t wo) {
+  // the MFMA kernel addresses x and grad_y with 32-bit element offsets
+  return batch * in_channels * height * width < ((int64_t)1 << 32) && batch * out_channels * ho * wo < ((int64_t)1 << 32);
+}
+int train_backward(int32_t n_qubits, const void* x, bool x32, int64_t batch, int64_t in_channels, int64_t height,
+                   int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, const double* grad_y,
+                   int64_t out_channels, const float* rows, int32_t row_channels, float* grad_features_t,
+                   float* h_partials, double* grad_x, void* stream);
+}  // namespace
+}  // extern "C++"
+
+int32_t qiddm_qconv_train_x32_ok(int64_t batch, int64_t in_channels, int64_t height, int64_t width, int64_t kh,
+                                 int64_t kw, int64_t pad_h, int64_t pad_w, int64_t out_channels, int32_t row_channels) {
+  if (batch < 1 || in_channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad_h < 0 || pad_w < 0 ||
+      out_channels < 1)
+    return 0;
+  const int64_t ho = height + 2 * pad_h - kh + 1, wo = width + 2 * pad_w - kw + 1;
+  if (ho < 1 || wo < 1) return 0;
+  const int64_t f = in_channels * kh * kw;
+  return train_mfma_choice(f, row_channels, train_fits32(batch, in_channels, height, width, out_channels, ho, wo), true,
+                           kh, kw, in_channels)
+                 .kern != nullptr
+             ? 1
+             : 0;
+}
+
 int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch, int64_t in_channels, int64_t height,
                                int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
                                const double* grad_y, int64_t out_channels, const float* rows, int32_t row_channels,
                                float* grad_features_t, float* h_partials, double* grad_x, void* stream) {
+  return train_backward(n_qubits, x, false, batch, in_channels, height, width, kh, kw, pad_h, pad_w, grad_y,
+                        out_channels, rows, row_channels, grad_features_t, h_partials, grad_x, stream);
+}
+
+int qiddm_qconv_train_backward_x32(int32_t n_qubits, const float* x, int64_t batch, int64_t in_channels,
+                                   int64_t height, int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
+                                   const double* grad_y, int64_t out_channels, const float* rows,
+                                   int32_t row_channels, float* grad_features_t, float* h_partials, double* grad_x,
+                                   void* stream) {
+  return train_backward(n_qubits, x, true, batch, in_channels, height, width, kh, kw, pad_h, pad_w, grad_y,
+                        out_channels, rows, row_channels, grad_features_t, h_partials, grad_x, stream);
+}
+
+namespace {
+int train_backward(int32_t n_qubits, const void* x, bool x32, int64_t batch, int64_t in_channels, int64_t height,
+                   int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, const double* grad_y,
+                   int64_t out_channels, const float* rows, int32_t row_channels, float* grad_features_t,
+                   float* h_partials, double* grad_x, void* stream) {
   if (n_qubits < 1 || n_qubits > 12) return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d outside 1..12", n_qubits);
   if (batch < 1 || in_channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad_h < 0 || pad_w < 0 ||
       out_channels < 1)
@@ -292,34 +387,17 @@ int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch,
   size_t smem = 0;
   const void* kern = nullptr;
   unsigned threads = qiddm::kTcThreads;
-  // the three products on the f32 matrix cores (qsim_qconv_train_mfma.h) from 32 patch features on and whenever its
-  // LDS tiles fit; the VALU kernel keeps the narrowest layers (9 / 16 features: the whole backward of the layer measured
-  // 0.37 / 0.55 ms against 0.53 / 0.67 on the MFMA kernel at 2560 x 28 x 28 pixels, tools/stamp_qconv_train.py; from 32
-  // features on the MFMA kernel wins by 0.05 - 0.33 ms per layer) and the widest.  QIDDM_QCONV_VALU=1 / QIDDM_QCONV_MFMA=1:
-  // kernel experiments (A/B on the same box)
-  static const bool env_mfma = std::getenv("QIDDM_QCONV_MFMA") != nullptr;
-  static const bool env_valu = std::getenv("QIDDM_QCONV_VALU") != nullptr;
-  // the MFMA kernel addresses x and grad_y with 32-bit element offsets
-  const bool fits32 = batch * in_channels * height * width < ((int64_t)1 << 32) &&
-                      batch * out_channels * ho * wo < ((int64_t)1 << 32);
-  const bool force_valu = env_valu || !fits32 || (f < 32 && !env_mfma);
-  const int jbm = (int)((qiddm::tm_fcols((int)f) / 16 + qiddm::kTmWaves - 1) / qiddm::kTmWaves);
-#define QIDDM_TM_CASE(CO, J)                                                                                     \
-  if (!kern && !force_valu && row_channels == CO && jbm <= J && qiddm::tm_lds_bytes<CO>((int)f) <= kMaxLds) {   \
-    smem = qiddm::tm_lds_bytes<CO>((int)f);                                                                      \
-    kern = reinterpret_cast<const void*>(qiddm::qconv_train_backward_mfma_kernel<CO, J>);                        \
-    threads = qiddm::kTmThreads;                                                                                 \
+  // the three products on the f32 matrix cores (qsim_qconv_train_mfma.h) where train_mfma_choice() says so
+  const TmChoice tm = train_mfma_choice(f, row_channels,
+                                        train_fits32(batch, in_channels, height, width, out_channels, ho, wo), x32, kh, kw,
+                                        in_channels);
+  if (tm.kern) {
+    kern = tm.kern;
+    smem = tm.smem;
+    threads = qiddm::kTmThreads;
+  } else if (x32) {
+    return fail(QIDDM_ERR_UNSUPPORTED, "float32 x is taken by the matrix-core kernel only (qiddm_qconv_train_x32_ok)");
   }
-  QIDDM_TM_CASE(8, 2)
-  QIDDM_TM_CASE(8, 4)
-  QIDDM_TM_CASE(8, 8)
-  QIDDM_TM_CASE(16, 2)
-  QIDDM_TM_CASE(16, 4)
-  QIDDM_TM_CASE(16, 8)
-  QIDDM_TM_CASE(32, 2)
-  QIDDM_TM_CASE(32, 4)
-  QIDDM_TM_CASE(32, 8)
-#undef QIDDM_TM_CASE
 #define QIDDM_TC_CASE(CO, J)                                                                      \
   if (!kern && row_channels == CO && jch == J) {                                                           \
     smem = qiddm::tc_lds_bytes<CO>((int)f);                                                       \
@@ -349,6 +427,7 @@ int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch,
   }
   return QIDDM_OK;
 }
+}  // namespace
 
 int qiddm_qconv_fold_features(const float* grad_features_t, int64_t batch, int64_t in_channels, int64_t height,
                               int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, double* grad_x,

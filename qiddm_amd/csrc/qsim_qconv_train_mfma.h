@@ -42,8 +42,12 @@ __host__ __device__ inline size_t tm_lds_bytes(int F) {
          (size_t)F * sizeof(uint32_t);
 }
 
-template <int CO, int JBMAX>
-__global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_backward_mfma_kernel(const double* __restrict__ x,
+// XT: element type of x -- the float64 activations as the reference holds them, or a float32 copy (same values after
+// the (float) conversion every patch element goes through here; half the registers per load in flight)
+// SK, SC: kernel extent (SK x SK) and input channels as compile-time constants (0: run-time).  With both known the walk
+// over a wave's patch columns has no control flow at all: three instructions per load instead of ~25 and three branches
+template <int CO, int JBMAX, typename XT, int SK = 0, int SC = 0>
+__global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_backward_mfma_kernel(const XT* __restrict__ x,
                                                                                const double* __restrict__ gy,
                                                                                const float* __restrict__ rt,
                                                                                float* __restrict__ gfeat_t,
@@ -74,11 +78,6 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
     s_rt[i] = v;
   }
   for (int i = tid; i < kTmTile * FS; i += kTmThreads) s_v[i] = 0.f;
-  for (int f = tid; f < F; f += kTmThreads) {
-    const int dj = f % tc.kw, t = f / tc.kw;
-    const int di = t % tc.kh, c = t / tc.kh;
-    s_tap[f] = (uint32_t)((c * tc.H + di) * tc.W + dj) | ((uint32_t)di << 24) | ((uint32_t)dj << 28);
-  }
   // persistent accumulators of product (3): this wave's feature-column blocks jb = q, q + 4, ...
   f32x4 acch[JBMAX][NBC];
 #pragma unroll
@@ -105,14 +104,51 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
   // covered that way (all of them up to 4 PRE features); the rest is fetched, 16 at a time, when the tile starts.
   // register budget: 2 waves per SIMD; the JBMAX = 8 variants (>= 256 patch features: > 80 KB of LDS, one workgroup per
   // CU anyway) are compiled for one and prefetch deeper
-  constexpr int PRE = JBMAX <= 2 ? 32 : (JBMAX <= 4 ? (CO <= 16 ? 36 : 16) : 40);
+  constexpr bool X32 = sizeof(XT) == 4;
+  constexpr int PRE = X32 ? (JBMAX <= 2 ? 32 : (JBMAX <= 4 ? (CO <= 16 ? 48 : 16) : 64))
+                          : (JBMAX <= 2 ? (CO <= 16 ? 32 : 24) : (JBMAX <= 4 ? (CO == 8 ? 28 : (CO == 16 ? 20 : 8)) : 40));
   constexpr int GC = CO / kTmWaves;
-  double raw[PRE], graw[GC];
+  static_assert(PRE <= 64, "one in-image bit per prefetched column in a 64-bit mask");
+  XT raw[PRE];
+  double graw[GC];
   uint64_t inb_mask = 0;
   uint32_t glive_mask = 0;
   int g_i0 = 0, g_j0 = 0;
-  uint32_t g_img = 0;   // element offset of this pixel's patch origin in x (the host checks numel(x), numel(gy) < 2^32):
-                        // 32-bit offsets from the kernel-argument base keep a load's address in ONE register
+  // This wave's patch columns are walked in (tap, channel) order -- tap t = di kw + dj, then its channels c = q, q + 4,
+  // ... -- by scalar counters: the clamped element offset of a tap (and whether the tap lies inside the image) is
+  // per-lane work done once per TAP, and a column costs one add, the address and the load.  (A tap table in LDS made
+  // every load wait for its own LDS round trip; per-column tap arithmetic cost ~30 instructions a load: issuing a
+  // tile's loads was 31 % of the tile either way.)  Column index of (t, c): j = c kh kw + t.
+  constexpr bool STATIC = SK > 0 && SC > 0;
+  static_assert(!STATIC || SC % kTmWaves == 0, "the static walk deals whole channels to the four waves");
+  constexpr int SKK = SK * SK, SCQ = SC / kTmWaves, SCOLS = SKK * SCQ;   // taps, channels and columns of a wave
+  const int KK = STATIC ? SKK : tc.kh * tc.kw;
+  const uint32_t plane = (uint32_t)(tc.H * tc.W);
+  uint32_t g_base = 0;  // element offset of this pixel's image in x (the host checks numel(x), numel(gy) < 2^32): 32-bit
+                        // offsets from the kernel-argument base keep a load's address in ONE register
+  struct Walk {
+    int t, di, dj, c;   // wave-uniform
+  };
+  Walk rest{0, 0, 0, 0};  // where the prefetched columns of the tile in flight end
+  // per-lane: offset of tap (di, dj) of this lane's pixel clamped into the image (zero padding reads the nearest in-image
+  // element and is zeroed afterwards: NOT one shared dummy address, which serialises the grid on one L2 channel)
+  auto tap_offset = [&](const Walk& w, bool& inside) -> uint32_t {
+    const int ii = g_i0 + w.di, jj = g_j0 + w.dj;
+    const int iic = min(max(ii, 0), tc.H - 1), jjc = min(max(jj, 0), tc.W - 1);
+    inside = ii == iic && jj == jjc;
+    return g_base + __umul24((uint32_t)iic, (uint32_t)tc.W) + (uint32_t)jjc;
+  };
+  auto advance = [&](Walk& w) -> bool {   // next column; true when the tap changed
+    w.c += kTmWaves;
+    if (w.c < tc.C) return false;
+    w.c = q;
+    ++w.t;
+    if (++w.dj == tc.kw) {
+      w.dj = 0;
+      ++w.di;
+    }
+    return true;
+  };
   auto issue_gather = [&](int64_t tile) {
     const int64_t m_raw = tile * kTmTile + lane;
     const bool valid = m_raw < tc.M;
@@ -123,7 +159,6 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
     const int oi = pix / tc.Wo, oj = pix - oi * tc.Wo;
     g_i0 = oi - tc.ph;
     g_j0 = oj - tc.pw;
-    g_img = (uint32_t)((int64_t)b * tc.C * tc.H * tc.W + (int64_t)g_i0 * tc.W + g_j0);   // may wrap; in-image taps undo it
     const uint32_t gpix = (uint32_t)(b * tc.C_out * pixels + pix);
     glive_mask = 0;
 #pragma unroll
@@ -134,20 +169,38 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
       graw[cu] = 0.0;
       if (c < tc.C_out) graw[cu] = gy[gpix + (uint32_t)c * (uint32_t)pixels];   // wave-uniform; tail pixels read pixel M - 1
     }
-    // no per-lane branch around a load: an out-of-image tap (zero padding) reads the nearest in-image element of its
-    // plane instead and is zeroed afterwards (NOT one shared dummy address: every wave of the grid hammering x[0] queues
-    // up on a single L2 channel), so all loads of the wave are in flight together; `j < F` is wave-uniform
     inb_mask = 0;
+    g_base = (uint32_t)((int64_t)b * tc.C * tc.H * tc.W);
+    if constexpr (STATIC) {   // column u = t * SCQ + ci: tap t, channel q + 4 ci
+      const uint32_t qplane = (uint32_t)q * plane;
 #pragma unroll
-    for (int u = 0; u < PRE; ++u) {
-      const int j = q + kTmWaves * u;
-      if (j < F) {
-        const uint32_t tap = s_tap[j];
-        const int ii = g_i0 + (int)((tap >> 24) & 15u), jj = g_j0 + (int)(tap >> 28);
-        const int iic = ii < 0 ? 0 : (ii >= tc.H ? tc.H - 1 : ii), jjc = jj < 0 ? 0 : (jj >= tc.W ? tc.W - 1 : jj);
-        inb_mask |= (uint64_t)(ii == iic && jj == jjc) << u;
-        raw[u] = x[g_img + (tap & 0xffffffu) + (uint32_t)((iic - ii) * tc.W + (jjc - jj))];
+      for (int t = 0; t < SKK; ++t) {
+        if (t * SCQ < PRE) {
+          bool inside = false;
+          const uint32_t off = tap_offset(Walk{t, t / SK, t % SK, 0}, inside) + qplane;
+#pragma unroll
+          for (int ci = 0; ci < SCQ; ++ci) {
+            const int u = t * SCQ + ci;
+            if (u < PRE) {
+              raw[u] = x[off + (uint32_t)(kTmWaves * ci) * plane];
+              inb_mask |= (uint64_t)inside << u;
+            }
+          }
+        }
       }
+    } else {
+      Walk w{q < tc.C ? 0 : KK, 0, 0, q};   // a wave beyond the channel count owns no column
+      bool inside = false;
+      uint32_t off = w.t < KK ? tap_offset(w, inside) : 0u;
+#pragma unroll
+      for (int u = 0; u < PRE; ++u) {
+        if (w.t < KK) {
+          raw[u] = x[off + (uint32_t)w.c * plane];
+          inb_mask |= (uint64_t)inside << u;
+          if (advance(w) && w.t < KK) off = tap_offset(w, inside);
+        }
+      }
+      rest = w;
     }
   };
   __syncthreads();  // s_tap is staged
@@ -158,40 +211,80 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
     __syncthreads();  // the previous tile's readers of s_v / s_w / s_w3 are done (and the tables are staged)
     {
       float n2 = 0.f;
+      if constexpr (STATIC) {
+        float* __restrict__ vrow = s_v + (size_t)lane * FS + q * SKK;   // column of (t, ci): (q + 4 ci) SKK + t
 #pragma unroll
-      for (int u = 0; u < PRE; ++u) {
-        const int j = q + kTmWaves * u;
-        if (j < F) {
+        for (int u = 0; u < (PRE < SCOLS ? PRE : SCOLS); ++u) {
+          const int t = u / SCQ, ci = u % SCQ;
           const float v = (((inb_mask >> u) & 1) ? (float)raw[u] : 0.f) + 0.1f;
-          s_v[lane * FS + j] = v;
+          vrow[kTmWaves * ci * SKK + t] = v;
           n2 = fmaf(v, v, n2);
         }
-      }
-      // wide layers (more than 4 PRE patch columns): the remaining columns, sixteen loads in flight at a time
-      constexpr int GU = 16;
-      for (int j0g = q + kTmWaves * PRE; j0g < F; j0g += kTmWaves * GU) {
-        double more[GU];
-        bool inb[GU];
+        // wide layers: the columns past the prefetch, sixteen loads in flight at a time
+        constexpr int GU = 16;
+        const uint32_t qplane = (uint32_t)q * plane;
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
-          const int j = j0g + kTmWaves * u;
-          inb[u] = false;
-          more[u] = 0.0;
-          if (j < F) {
-            const uint32_t tap = s_tap[j];
-            const int ii = g_i0 + (int)((tap >> 24) & 15u), jj = g_j0 + (int)(tap >> 28);
-            const int iic = ii < 0 ? 0 : (ii >= tc.H ? tc.H - 1 : ii), jjc = jj < 0 ? 0 : (jj >= tc.W ? tc.W - 1 : jj);
-            inb[u] = ii == iic && jj == jjc;
-            more[u] = x[g_img + (tap & 0xffffffu) + (uint32_t)((iic - ii) * tc.W + (jjc - jj))];
+        for (int u0 = PRE; u0 < SCOLS; u0 += GU) {
+          XT more[GU];
+          uint32_t inb = 0;
+#pragma unroll
+          for (int k = 0; k < GU; ++k) {
+            const int u = u0 + k;
+            if (u < SCOLS) {
+              const int t = u / SCQ, ci = u % SCQ;
+              bool inside = false;
+              const uint32_t off = tap_offset(Walk{t, t / SK, t % SK, 0}, inside) + qplane;
+              more[k] = x[off + (uint32_t)(kTmWaves * ci) * plane];
+              inb |= (uint32_t)inside << k;
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < GU; ++k) {
+            const int u = u0 + k;
+            if (u < SCOLS) {
+              const int t = u / SCQ, ci = u % SCQ;
+              const float v = (((inb >> k) & 1) ? (float)more[k] : 0.f) + 0.1f;
+              vrow[kTmWaves * ci * SKK + t] = v;
+              n2 = fmaf(v, v, n2);
+            }
           }
         }
+      } else {
+        Walk w{q < tc.C ? 0 : KK, 0, 0, q};
 #pragma unroll
-        for (int u = 0; u < GU; ++u) {
-          const int j = j0g + kTmWaves * u;
-          if (j < F) {
-            const float v = (inb[u] ? (float)more[u] : 0.f) + 0.1f;
-            s_v[lane * FS + j] = v;
+        for (int u = 0; u < PRE; ++u) {
+          if (w.t < KK) {
+            const float v = (((inb_mask >> u) & 1) ? (float)raw[u] : 0.f) + 0.1f;
+            s_v[lane * FS + w.c * KK + w.t] = v;
             n2 = fmaf(v, v, n2);
+            advance(w);
+          }
+        }
+        // wide layers (more than 4 PRE patch columns): the remaining columns, sixteen loads in flight at a time
+        constexpr int GU = 16;
+        w = rest;
+        while (w.t < KK) {
+          XT more[GU];
+          uint32_t inb = 0;
+          Walk wl = w;
+          bool inside = false;
+          uint32_t off = tap_offset(w, inside);
+#pragma unroll
+          for (int u = 0; u < GU; ++u) {
+            if (w.t < KK) {
+              more[u] = x[off + (uint32_t)w.c * plane];
+              inb |= (uint32_t)inside << u;
+              if (advance(w) && w.t < KK) off = tap_offset(w, inside);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < GU; ++u) {
+            if (wl.t < KK) {
+              const float v = (((inb >> u) & 1) ? (float)more[u] : 0.f) + 0.1f;
+              s_v[lane * FS + wl.c * KK + wl.t] = v;
+              n2 = fmaf(v, v, n2);
+              advance(wl);
+            }
           }
         }
       }
@@ -323,6 +416,8 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
     // the next tile's global loads go out now (behind this tile's stores in the memory queue) and land while
     // product (3) runs and the workgroup crosses the barrier
     if (tile + gridDim.x < tiles) issue_gather(tile + gridDim.x);
+    mark(4);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- (3) h += (W2 / |v|)^T v over the tile's 64 pixels: this wave's 16-column blocks; chunks of two k-steps
     //      (8 pixels), the fragments of chunk c + 1 in flight while the MFMAs of chunk c issue
     {

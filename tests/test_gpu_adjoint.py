@@ -133,6 +133,43 @@ def test_fused_qconv_backward_vs_oracle_autograd(c_in, c_out, k, pad, hw, qdepth
     assert torch.allclose(xg.grad.cpu(), xo.grad, atol=tol * sx * 10), (xg.grad.cpu() - xo.grad).abs().max()
 
 
+@pytest.mark.parametrize("c_in,c_out,k,pad,hw", [
+    (16, 8, 3, 1, (28, 28)),     # unet_simple shapes with the kernel extent / channel count compiled in ...
+    (8, 16, 3, 1, (14, 14)),
+    (32, 16, 1, 0, (14, 14)),
+    (32, 16, 3, 1, (14, 14)),
+    (16, 32, 3, 1, (7, 7)),
+    (12, 8, 3, 1, (9, 11)),      # ... and run-time shapes: 108 features, channels not a multiple of the four waves
+    (6, 16, 5, 2, (8, 8)),       # 150 features, 5 x 5 taps
+    (40, 8, 1, 0, (6, 6)),       # 1 x 1, 40 features
+])
+def test_thin_product_backward_float32_activations_and_generic_walk(c_in, c_out, k, pad, hw, monkeypatch):
+    """qiddm_qconv_train_backward_x32 (float32 copy of the activations) == qiddm_qconv_train_backward bit for bit:
+    every patch element is converted to float32 before the products either way.  The last three shapes have no
+    compiled-in variant and take the run-time walk of the gather; all of them against autograd through the oracle."""
+    from qiddm_amd import nn, circuit
+    torch.manual_seed(5)
+    layer = nn.QConv2d(c_in, c_out, k, pad, 2).cuda().train()
+    x = torch.rand(3, c_in, *hw, dtype=torch.float64, device="cuda")
+    gy = torch.randn(3, c_out, hw[0] + 2 * pad - k + 1, hw[1] + 2 * pad - k + 1, dtype=torch.float64, device="cuda")
+
+    def grads(x32):
+        monkeypatch.setattr(circuit, "_QCONV_X32", x32)
+        xg = x.clone().requires_grad_(True)
+        gx, gw = torch.autograd.grad(layer(xg), [xg, layer.weights], gy)
+        return gx, gw
+
+    gx64, gw64 = grads(False)
+    gx32, gw32 = grads(True)
+    assert torch.equal(gx64, gx32) and torch.equal(gw64, gw32)
+    # against autograd through the oracle
+    xo = x.cpu().requires_grad_(True)
+    wo = layer.weights.detach().cpu().clone().requires_grad_(True)
+    (oc.qconv2d_forward(xo, wo, c_out, (k, k), (pad, pad)) * gy.cpu()).sum().backward()
+    assert torch.allclose(gx64.cpu(), xo.grad, atol=2e-3 * max(1.0, xo.grad.abs().max().item()))
+    assert torch.allclose(gw64.cpu(), wo.grad, atol=2e-3 * max(1.0, wo.grad.abs().max().item()))
+
+
 def test_differn_backprop_training_step():
     """differN (diff_method='backprop') end to end: chained rounds, grads == oracle autograd."""
     from qiddm_amd import nn, set_default_precision

@@ -27,4 +27,4 @@ for (cin, cout, k, pad, side) in [(1, 8, 3, 1, 28), (16, 8, 1, 0, 28), (16, 8, 3
     dt = (time.perf_counter() - t0) / 5
     n = max(t[5], 1)
     print(f"C{cin}->{cout} k{k} {side}x{side} (F={cin*k*k}): tiles/WG {t[5]}  per tile: gather {t[0]//n}  prod1+epi {t[1]//n}  "
-          f"prod2+store {t[2]//n}  prod3 {t[3]//n} ticks;  whole backward {dt*1e3:.3f} ms")
+          f"prod2+store {t[2]//n}  next-gather issue {t[4]//n}  prod3 {t[3]//n} ticks;  whole backward {dt*1e3:.3f} ms")
