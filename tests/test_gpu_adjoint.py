@@ -292,8 +292,6 @@ def test_wide_cz_adjoint_vs_oracle_autograd(n, L, S, meas, B, precision, tol):
     either local-bit set), every layer a block start (S = 1), both read-outs, 11 .. 16 qubits, both precisions."""
     from oracle import circuits as oc
     from qiddm_amd.circuit import Circuit, run_adjoint
-    if n == 16 and (precision == "f64" or L * S > 2) and meas == "probs":
-        pytest.skip("oracle time")
     g_ = torch.Generator().manual_seed(1000 * n + 10 * L + S)
     circ = Circuit(n_qubits=n, encoding="rz", imprimitive="CZ", measure=meas, n_rounds=1, n_blocks=L, sel_layers=S)
     w = torch.randn(circ.angles_shape, generator=g_, dtype=torch.float64) * 0.6

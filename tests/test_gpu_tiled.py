@@ -36,8 +36,6 @@ def _run(circ, x, w, precision):
 @pytest.mark.parametrize("n", [11, 12, 13, 14, 15, 16])
 @pytest.mark.parametrize("imp,meas", [("CZ", "expz"), ("CZ", "probs"), ("CNOT", "probs"), ("CNOT", "expz")])
 def test_rz_reupload_wide(n, imp, meas, precision):
-    if precision == "f64" and n > 13 and imp == "CNOT":
-        pytest.skip("covered at f32; keeps the oracle time down")
     batch = 5 if n <= 13 else 2
     circ, spec, x, w = _mk(n, "rz", imp, meas, N=1, L=2, S=3, batch=batch, seed=n * 7)
     got = _run(circ, x, w, precision)
@@ -122,8 +120,6 @@ def test_param_shift_wide(enc, imp, meas):
 def test_wide_cz_layer_counts(n, L, S, meas, precision):
     """1 layer (the generated product state is measured directly), even / odd layer counts (the last pass runs on
     either local-bit set), every layer a block start (S = 1: data re-upload in every diagonal)."""
-    if n == 16 and (precision == "f64" or meas == "probs") and L * S > 3:
-        pytest.skip("oracle time")
     circ, spec, x, w = _mk(n, "rz", "CZ", meas, N=1, L=L, S=S, batch=3, seed=100 * n + 10 * L + S)
     got = _run(circ, x, w, precision)
     ref = oc.run_circuit(spec, x, w)
