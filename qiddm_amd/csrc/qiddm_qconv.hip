@@ -211,18 +211,24 @@ int qiddm_qconv_unitary_forward(int32_t n_qubits, const double* u, const double*
   if (const char* ev = std::getenv("QIDDM_STAMP_PTR")) gc.stamps = reinterpret_cast<unsigned long long*>(std::strtoull(ev, nullptr, 0));
   const int64_t mblocks = (g.m + qiddm::kGemmM - 1) / qiddm::kGemmM;
   if (mblocks > 0x7fffffff) return fail(QIDDM_ERR_UNSUPPORTED, "too many output pixels for one launch");
+#define QIDDM_GEMM_LAUNCH(GRID_Y, ...)                                                                             \
+  do {                                                                                                            \
+    if (upsample2x)                                                                                               \
+      hipLaunchKernelGGL((qiddm::__VA_ARGS__ true>), dim3((unsigned)mblocks, (unsigned)(GRID_Y)),                  \
+                         dim3(4 * qiddm::kWave), 0, st, x, w, padv, bnv, y, gc);                                  \
+    else                                                                                                          \
+      hipLaunchKernelGGL((qiddm::__VA_ARGS__ false>), dim3((unsigned)mblocks, (unsigned)(GRID_Y)),                 \
+                         dim3(4 * qiddm::kWave), 0, st, x, w, padv, bnv, y, gc);                                  \
+  } while (0)
   if (g.packed == 3)
-    hipLaunchKernelGGL(qiddm::qconv_gemm_wide_kernel, dim3((unsigned)mblocks, (unsigned)(g.n_pad / 256)),
-                       dim3(4 * qiddm::kWave), 0, st, x, w, padv, bnv, y, gc);
+    QIDDM_GEMM_LAUNCH(g.n_pad / 256, qconv_gemm_wide_kernel<);
   else if (g.packed == 2)
-    hipLaunchKernelGGL(qiddm::qconv_gemm_kernel<2>, dim3((unsigned)mblocks, 1u), dim3(4 * qiddm::kWave), 0, st, x, w,
-                       padv, bnv, y, gc);
+    QIDDM_GEMM_LAUNCH(1, qconv_gemm_kernel<2,);
   else if (g.packed == 1)
-    hipLaunchKernelGGL(qiddm::qconv_gemm_kernel<1>, dim3((unsigned)mblocks, 1u), dim3(4 * qiddm::kWave), 0, st, x, w,
-                       padv, bnv, y, gc);
+    QIDDM_GEMM_LAUNCH(1, qconv_gemm_kernel<1,);
   else
-    hipLaunchKernelGGL(qiddm::qconv_gemm_kernel<0>, dim3((unsigned)mblocks, (unsigned)(g.n_pad / 64)),
-                       dim3(4 * qiddm::kWave), 0, st, x, w, padv, bnv, y, gc);
+    QIDDM_GEMM_LAUNCH(g.n_pad / 64, qconv_gemm_kernel<0,);
+#undef QIDDM_GEMM_LAUNCH
   e = hipGetLastError();
   if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_gemm_kernel launch failed: %s", hipGetErrorString(e));
   return QIDDM_OK;

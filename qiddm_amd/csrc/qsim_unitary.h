@@ -148,7 +148,10 @@ constexpr int kGemmMaxK = 4096;  // F <= D <= 2^12 on this route
 // MODE 0: 32 channels per workgroup, separate Re / Im tiles.  MODE 1 (C_out <= 16): Re and Im columns share one
 // 32-wide tile (one accumulator, half the MFMAs).  MODE 2 (C_out <= 8): 16 columns on v_mfma_f32_16x16x4_f32
 // (two 16-row tiles per wavefront, 32 cycles each): no padding columns at the 8-channel layers of unet_simple.
-template <int MODE>
+// UP (compile time = g.upsample): the bilinear x2 in front of an up_conv folded into the gather.  As a run-time branch
+// its four-load taps shared registers with the plain path, and the wait-count pass then drained the plain path's gather
+// before the chunk's MFMAs (vmcnt waits between the B loads)
+template <int MODE, bool UP>
 __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __restrict__ x,
                                                                const float* __restrict__ w,
                                                                const float* __restrict__ padv,
@@ -173,12 +176,12 @@ __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __r
   const bool stamp = g.stamps != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
   if (stamp) g.stamps[0] = __builtin_amdgcn_s_memtime();
   const int khw = g.kh * g.kw;
-  const size_t plane = g.upsample ? (size_t)g.Hs * g.Ws : (size_t)g.H * g.W;
+  const size_t plane = UP ? (size_t)g.Hs * g.Ws : (size_t)g.H * g.W;
   for (int f = tid; f < g.K_pad; f += 4 * kWave) {
     const int c = f / khw, rem = f - c * khw;
     const int di = rem / g.kw, dj = rem - di * g.kw;
     // (upsample: the offset field carries the channel; the taps are interpolated)
-    const uint32_t off = g.upsample ? (uint32_t)c : (uint32_t)(c * plane) + (uint32_t)(di * g.W + dj);
+    const uint32_t off = UP ? (uint32_t)c : (uint32_t)(c * plane) + (uint32_t)(di * g.W + dj);
     s_tap[f] = off | ((uint32_t)di << 24) | ((uint32_t)dj << 28);
   }
   // ---- this thread's staging duty: row m_s, KT consecutive k of every chunk ------------------------------
@@ -197,11 +200,13 @@ __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __r
 
   // registers of the chunk in flight: the gather for chunk k+1 is issued before the MFMAs of chunk k
   double pv[KT];
+  uint32_t in_mask = 0;   // bit u: tap u of the chunk in flight lies inside the image
   float bv[(kGemmK * NB) / (4 * kWave)];
   auto fetch = [&](int k0) {
     // branch-free: every load goes to a valid address (the image origin when the tap is outside) so that all KT
     // of them are in flight together; the select happens on the loaded value
     uint32_t tap[KT];
+    in_mask = 0;
 #pragma unroll
     for (int u = 0; u < KT; ++u) tap[u] = s_tap[k0 + kh_s + u];
 #pragma unroll
@@ -210,12 +215,16 @@ __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __r
       const int ii = oi + (int)((tap[u] >> 24) & 15u), jj = oj + (int)(tap[u] >> 28);
       const uint32_t off = tap[u] & 0xFFFFFFu;
       const bool in = m_ok && f < g.F && ii >= 0 && ii < g.H && jj >= 0 && jj < g.W;
-      double v;
-      if (g.upsample)
-        v = bilinear2x(img + (in ? (size_t)off * plane : 0), g.Hs, g.Ws, in ? ii : 0, in ? jj : 0);
-      else
-        v = *(in ? corner + off : img);
-      pv[u] = in ? v : 0.0;
+      // the select on the loaded value is deferred to stage(): done here it put a wait for the gather in front of
+      // the chunk's MFMAs (s_waitcnt vmcnt right after the issue), i.e. the load latency on the critical path
+      if constexpr (UP) {
+        const double v = bilinear2x(img + (in ? (size_t)off * plane : 0), g.Hs, g.Ws, in ? ii : 0, in ? jj : 0);
+        pv[u] = in ? v : 0.0;
+        in_mask |= 1u << u;
+      } else {
+        pv[u] = *(in ? corner + off : img);
+        in_mask |= (uint32_t)in << u;
+      }
     }
 #pragma unroll
     for (int i = 0; i < (kGemmK * NB) / (4 * kWave); ++i) {
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __r
       const int f = k0 + kh_s + u;
       float v = 0.f;
       if (m_ok && f < g.F) {
-        v = (float)(pv[u] + 0.1);
+        v = (float)((((in_mask >> u) & 1u) ? pv[u] : 0.0) + 0.1);
         n2 = fmaf(v, v, n2);
       }
       s_a[kh_s + u][m_s] = v;
@@ -352,31 +361,31 @@ __global__ __launch_bounds__(4 * kWave) void qconv_gemm_kernel(const double* __r
 constexpr int kWideSub = 4;
 constexpr int kWideK = 16;
 
-__global__ __launch_bounds__(4 * kWave, 2) void qconv_gemm_wide_kernel(const double* __restrict__ x,
+template <bool UP>
+__global__ __launch_bounds__(4 * kWave, UP ? 1 : 2) void qconv_gemm_wide_kernel(const double* __restrict__ x,
                                                                     const float* __restrict__ w,
                                                                     const float* __restrict__ padv,
                                                                     const double* __restrict__ bn,
                                                                     double* __restrict__ y, const GemmConv g) {
   constexpr int NBW = 64 * kWideSub;  // B columns per workgroup
   constexpr int KT = kWideK / 2;
+  // two staging buffers: chunk k + 1 is written while chunk k feeds the matrix cores, ONE barrier per chunk
   constexpr int kStageBytes = (kWideK * kGemmM + kWideK * NBW) * 4;
   constexpr int kOutBytes = 32 * (kGemmM + 1) * 8;
-  __shared__ __attribute__((aligned(16))) unsigned char s_raw[kOutBytes > kStageBytes ? kOutBytes : kStageBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char s_raw[kOutBytes > 2 * kStageBytes ? kOutBytes : 2 * kStageBytes];
   __shared__ uint32_t s_tap[kGemmMaxK];
   __shared__ float s_n2[2][kGemmM];
   __shared__ float s_inv[kGemmM];
-  float (*s_a)[kGemmM] = reinterpret_cast<float (*)[kGemmM]>(s_raw);
-  float (*s_b)[NBW] = reinterpret_cast<float (*)[NBW]>(s_raw + kWideK * kGemmM * 4);
   double (*s_out)[kGemmM + 1] = reinterpret_cast<double (*)[kGemmM + 1]>(s_raw);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t m0 = (int64_t)blockIdx.x * kGemmM;
   const int ct0 = blockIdx.y * kWideSub;  // first 32-channel tile of this workgroup
   const int khw = g.kh * g.kw;
-  const size_t plane = g.upsample ? (size_t)g.Hs * g.Ws : (size_t)g.H * g.W;
+  const size_t plane = UP ? (size_t)g.Hs * g.Ws : (size_t)g.H * g.W;
   for (int f = tid; f < g.K_pad; f += 4 * kWave) {
     const int c = f / khw, rem = f - c * khw;
     const int di = rem / g.kw, dj = rem - di * g.kw;
-    const uint32_t off = g.upsample ? (uint32_t)c : (uint32_t)(c * plane) + (uint32_t)(di * g.W + dj);
+    const uint32_t off = UP ? (uint32_t)c : (uint32_t)(c * plane) + (uint32_t)(di * g.W + dj);
     s_tap[f] = off | ((uint32_t)di << 24) | ((uint32_t)dj << 28);
   }
   const int m_s = tid & (kGemmM - 1), kh_s = (tid >> 7) * KT;
@@ -392,9 +401,11 @@ __global__ __launch_bounds__(4 * kWave, 2) void qconv_gemm_wide_kernel(const dou
   __syncthreads();
 
   double pv[KT];
+  uint32_t in_mask = 0;   // bit u: tap u of the chunk in flight lies inside the image
   float bv[(kWideK * NBW) / (4 * kWave)];
   auto fetch = [&](int k0) {
     uint32_t tap[KT];
+    in_mask = 0;
 #pragma unroll
     for (int u = 0; u < KT; ++u) tap[u] = s_tap[k0 + kh_s + u];
 #pragma unroll
@@ -403,12 +414,16 @@ __global__ __launch_bounds__(4 * kWave, 2) void qconv_gemm_wide_kernel(const dou
       const int ii = oi + (int)((tap[u] >> 24) & 15u), jj = oj + (int)(tap[u] >> 28);
       const uint32_t off = tap[u] & 0xFFFFFFu;
       const bool in = m_ok && f < g.F && ii >= 0 && ii < g.H && jj >= 0 && jj < g.W;
-      double v;
-      if (g.upsample)
-        v = bilinear2x(img + (in ? (size_t)off * plane : 0), g.Hs, g.Ws, in ? ii : 0, in ? jj : 0);
-      else
-        v = *(in ? corner + off : img);
-      pv[u] = in ? v : 0.0;
+      // the select on the loaded value is deferred to stage(): done here it put a wait for the gather in front of
+      // the chunk's MFMAs (s_waitcnt vmcnt right after the issue), i.e. the load latency on the critical path
+      if constexpr (UP) {
+        const double v = bilinear2x(img + (in ? (size_t)off * plane : 0), g.Hs, g.Ws, in ? ii : 0, in ? jj : 0);
+        pv[u] = in ? v : 0.0;
+        in_mask |= 1u << u;
+      } else {
+        pv[u] = *(in ? corner + off : img);
+        in_mask |= (uint32_t)in << u;
+      }
     }
 #pragma unroll
     for (int i = 0; i < (kWideK * NBW) / (4 * kWave); ++i) {
@@ -416,13 +431,15 @@ __global__ __launch_bounds__(4 * kWave, 2) void qconv_gemm_wide_kernel(const dou
       bv[i] = w[(size_t)(k0 + e / NBW) * g.N_pad + ct0 * 64 + (e % NBW)];
     }
   };
-  auto stage = [&](int k0) {
+  auto stage = [&](int k0, int buf) {
+    float (*s_a)[kGemmM] = reinterpret_cast<float (*)[kGemmM]>(s_raw + buf * kStageBytes);
+    float (*s_b)[NBW] = reinterpret_cast<float (*)[NBW]>(s_raw + buf * kStageBytes + kWideK * kGemmM * 4);
 #pragma unroll
     for (int u = 0; u < KT; ++u) {
       const int f = k0 + kh_s + u;
       float v = 0.f;
       if (m_ok && f < g.F) {
-        v = (float)(pv[u] + 0.1);
+        v = (float)((((in_mask >> u) & 1u) ? pv[u] : 0.0) + 0.1);
         n2 = fmaf(v, v, n2);
       }
       s_a[kh_s + u][m_s] = v;
@@ -443,22 +460,41 @@ __global__ __launch_bounds__(4 * kWave, 2) void qconv_gemm_wide_kernel(const dou
       acc_im[sub][i] = 0.f;
     }
   fetch(0);
+  stage(0, 0);
+  __syncthreads();
+  int cur = 0;
   for (int k0 = 0; k0 < g.K_pad; k0 += kWideK) {
-    stage(k0);
-    __syncthreads();
-    if (k0 + kWideK < g.K_pad) fetch(k0 + kWideK);
-#pragma unroll
-    for (int kk = 0; kk < kWideK; kk += 2) {
-      const float a = s_a[kk + (lane >> 5)][wave * 32 + (lane & 31)];
+    const bool more = k0 + kWideK < g.K_pad;
+    if (more) fetch(k0 + kWideK);
+    const float (*s_a)[kGemmM] = reinterpret_cast<const float (*)[kGemmM]>(s_raw + cur * kStageBytes);
+    const float (*s_b)[NBW] = reinterpret_cast<const float (*)[NBW]>(s_raw + cur * kStageBytes + kWideK * kGemmM * 4);
+    // operands of k-step i + 1 are read from LDS while the eight MFMAs of step i issue (two register sets): as one
+    // read-then-use sequence the schedule was  wait - 2 MFMAs - read - wait - ...  and every pair of MFMAs (128 cycles
+    // of matrix-core time) waited out an LDS round trip of about that length
+    float fa[2], fb[2][2 * kWideSub];
+    auto read_step = [&](int buf, int kk) {
+      fa[buf] = s_a[kk + (lane >> 5)][wave * 32 + (lane & 31)];
 #pragma unroll
       for (int sub = 0; sub < kWideSub; ++sub) {
-        const float bre = s_b[kk + (lane >> 5)][sub * 64 + (lane & 31)];
-        const float bim = s_b[kk + (lane >> 5)][sub * 64 + 32 + (lane & 31)];
-        acc_re[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bre, acc_re[sub], 0, 0, 0);
-        acc_im[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bim, acc_im[sub], 0, 0, 0);
+        fb[buf][2 * sub] = s_b[kk + (lane >> 5)][sub * 64 + (lane & 31)];
+        fb[buf][2 * sub + 1] = s_b[kk + (lane >> 5)][sub * 64 + 32 + (lane & 31)];
       }
+    };
+    read_step(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < kWideK; kk += 2) {
+      const int buf = (kk >> 1) & 1;
+      if (kk + 2 < kWideK) read_step(buf ^ 1, kk + 2);
+#pragma unroll
+      for (int sub = 0; sub < kWideSub; ++sub) {
+        acc_re[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf], fb[buf][2 * sub], acc_re[sub], 0, 0, 0);
+        acc_im[sub] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[buf], fb[buf][2 * sub + 1], acc_im[sub], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the reads of step i + 1 in front of the MFMAs of step i
     }
+    if (more) stage(k0 + kWideK, cur ^ 1);
     __syncthreads();
+    cur ^= 1;
   }
   s_n2[tid >> 7][m_s] = n2;
   __syncthreads();
