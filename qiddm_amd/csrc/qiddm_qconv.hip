@@ -425,10 +425,7 @@ int train_backward(int32_t n_qubits, const void* x, bool x32, int64_t batch, int
   hipError_t e = hipLaunchKernel(kern, dim3(grid), dim3(threads), args, smem, st);
   if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_train_backward_kernel launch failed: %s", hipGetErrorString(e));
   if (grad_x) {
-    const int64_t total = batch * in_channels * height * width;
-    hipLaunchKernelGGL(qiddm::qconv_fold_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                       static_cast<const float*>(grad_features_t), grad_x, total, tc);
-    e = hipGetLastError();
+    e = qiddm::launch_fold_t(grad_features_t, grad_x, batch, tc, st);
     if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_fold_t_kernel launch failed: %s", hipGetErrorString(e));
   }
   return QIDDM_OK;
@@ -458,9 +455,7 @@ int qiddm_qconv_fold_features(const float* grad_features_t, int64_t batch, int64
   tc.Wo = (int32_t)wo;
   tc.F = (int32_t)(in_channels * kh * kw);
   tc.M = batch * ho * wo;
-  hipLaunchKernelGGL(qiddm::qconv_fold_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), grad_features_t, grad_x, total, tc);
-  const hipError_t e = hipGetLastError();
+  const hipError_t e = qiddm::launch_fold_t(grad_features_t, grad_x, batch, tc, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_fold_t_kernel launch failed: %s", hipGetErrorString(e));
   return QIDDM_OK;
 }

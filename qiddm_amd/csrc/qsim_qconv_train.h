@@ -282,28 +282,70 @@ __global__ __launch_bounds__(256) void qconv_vectors_kernel(const float* __restr
 }
 
 // dL/dx from the transposed feature gradients: every input element gathers the kh*kw patch entries it appeared in
-// (fixed order; neighbouring threads read neighbouring pixels of the same feature row: coalesced)
+// (fixed order; neighbouring threads read neighbouring pixels of the same feature row: coalesced).  One 64-bit
+// division per workgroup, 32-bit ones per element.  KH, KW > 0: the taps unrolled,
+// every load issued (to a clamped address) before the first add -- out-of-range taps add 0.0, which leaves the sum as the
+// branchy loop has it; 0: run-time extents.
+template <int KH, int KW>
 __global__ __launch_bounds__(256) void qconv_fold_t_kernel(const float* __restrict__ gfeat_t, double* __restrict__ gx,
                                                            int64_t total, const TrainConv tc) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
-  const int j = (int)(idx % tc.W);
-  int64_t t = idx / tc.W;
-  const int i = (int)(t % tc.H);
-  t /= tc.H;
-  const int c = (int)(t % tc.C);
-  const int64_t b = t / tc.C;
-  double accv = 0;
-  for (int di = 0; di < tc.kh; ++di) {
-    const int oi = i - di + tc.ph;
-    if (oi < 0 || oi >= tc.Ho) continue;
-    for (int dj = 0; dj < tc.kw; ++dj) {
-      const int oj = j - dj + tc.pw;
-      if (oj < 0 || oj >= tc.Wo) continue;
-      accv += (double)gfeat_t[(size_t)((c * tc.kh + di) * tc.kw + dj) * tc.M + (b * tc.Ho + oi) * tc.Wo + oj];
+  const int hw = tc.H * tc.W;
+  const int kh = KH > 0 ? KH : tc.kh, kw = KW > 0 ? KW : tc.kw;
+  // element -> (plane, i, j): one 64-bit division per workgroup (uniform), 32-bit ones per thread
+  const int64_t base = (int64_t)blockIdx.x * blockDim.x;
+  const int64_t pl0 = base / hw;
+  const uint32_t q = (uint32_t)(base - pl0 * hw) + threadIdx.x;
+  {
+    const int64_t pl = pl0 + q / (uint32_t)hw;
+    const int p = (int)(q % (uint32_t)hw);
+    if (pl * hw + p >= total) return;
+    const int i = p / tc.W, j = p - i * tc.W;
+    const int64_t b = pl / tc.C;
+    const int c = (int)(pl - b * tc.C);
+    const float* __restrict__ src = gfeat_t + (size_t)c * kh * kw * tc.M + (size_t)b * tc.Ho * tc.Wo;
+    double accv = 0;
+    if constexpr (KH > 0 && KW > 0) {
+      float v[KH * KW];
+#pragma unroll
+      for (int di = 0; di < KH; ++di) {
+        const int oi = i - di + tc.ph;
+        const int oic = min(max(oi, 0), tc.Ho - 1);
+#pragma unroll
+        for (int dj = 0; dj < KW; ++dj) {
+          const int oj = j - dj + tc.pw;
+          const int ojc = min(max(oj, 0), tc.Wo - 1);
+          const float ld = src[(size_t)(di * KW + dj) * tc.M + oic * tc.Wo + ojc];
+          v[di * KW + dj] = (oi == oic && oj == ojc) ? ld : 0.f;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < KH * KW; ++t) accv += (double)v[t];
+    } else {
+      for (int di = 0; di < kh; ++di) {
+        const int oi = i - di + tc.ph;
+        if (oi < 0 || oi >= tc.Ho) continue;
+        for (int dj = 0; dj < kw; ++dj) {
+          const int oj = j - dj + tc.pw;
+          if (oj < 0 || oj >= tc.Wo) continue;
+          accv += (double)src[(size_t)(di * kw + dj) * tc.M + oi * tc.Wo + oj];
+        }
+      }
     }
+    gx[pl * hw + p] = accv;
   }
-  gx[idx] = accv;
+}
+
+// host side of the launch (both entry points that fold)
+inline hipError_t launch_fold_t(const float* gfeat_t, double* gx, int64_t batch, const TrainConv& tc, hipStream_t st) {
+  const int64_t total = batch * tc.C * tc.H * tc.W;
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (tc.kh == 3 && tc.kw == 3)
+    hipLaunchKernelGGL((qconv_fold_t_kernel<3, 3>), grid, dim3(256), 0, st, gfeat_t, gx, total, tc);
+  else if (tc.kh == 1 && tc.kw == 1)
+    hipLaunchKernelGGL((qconv_fold_t_kernel<1, 1>), grid, dim3(256), 0, st, gfeat_t, gx, total, tc);
+  else
+    hipLaunchKernelGGL((qconv_fold_t_kernel<0, 0>), grid, dim3(256), 0, st, gfeat_t, gx, total, tc);
+  return hipGetLastError();
 }
 
 }  // namespace qiddm
