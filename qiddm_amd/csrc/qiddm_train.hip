@@ -100,8 +100,8 @@ int run_step(const qiddm_circuit_t* c, const qiddm_train_args_t* a, const Geomet
   d.grad_scale = (a->goal == 0 ? 2.0 : 0.2) / ((double)g.rows * (double)a->pixels);
   const bool q = d.train_quantum != 0;
   static const bool no_fold = std::getenv("QIDDM_NO_FOLD") != nullptr;  // kernel experiments: general reverse sweep
-  d.fold = (q && !no_fold && qiddm::can_fold(c->imprimitive, c->encoding) && N >= 2 &&
-            N <= qiddm::kFoldedAdjointMaxQubits) ? 1 : 0;
+  d.fold = (!no_fold && qiddm::can_fold(c->imprimitive, c->encoding) && N >= 2 &&
+            N <= qiddm::kFoldedAdjointMaxQubits) ? 1 : 0;   // (the forward-only step folds too)
   d.layers_per_round = c->n_blocks * c->sel_layers;
   p.fold = d.fold;
   hipError_t e;
@@ -128,7 +128,12 @@ int run_step(const qiddm_circuit_t* c, const qiddm_train_args_t* a, const Geomet
   int64_t k_blocks = (groups + WPB - 1) / WPB;
   if (k_blocks > kMaxRowBlocks) k_blocks = kMaxRowBlocks;
   int rc;
-  if (!q) {
+  if (!q && d.fold) {
+    if constexpr (N >= 2 && N <= qiddm::kFoldedAdjointMaxQubits)
+      rc = launch_rows<T, N, false, WPB, true>(a, g, ws, d, p, smem, k_blocks, st);
+    else
+      rc = fail(QIDDM_ERR_UNSUPPORTED, "folded forward is not instantiated for n_qubits=%d", N);
+  } else if (!q) {
     rc = launch_rows<T, N, false, WPB, false>(a, g, ws, d, p, smem, k_blocks, st);
   } else if (d.fold) {
     if constexpr (N >= 2 && N <= qiddm::kFoldedAdjointMaxQubits)

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(WPB* kWave, QUANTUM ? QIDDM_TRAIN_OCC : 1) void tra
   cur = smem_raw + (((size_t)(cur - smem_raw) + 7) & ~(size_t)7);
   double* s_gram = reinterpret_cast<double*>(cur);  // [N][N] G (row j' at s_gram[j' * N + j]), then c[N], s[N]
   T* s_gw_all = reinterpret_cast<T*>(s_gram + (N + 2) * N);
-  constexpr bool folded = QUANTUM && FOLD && N >= 2 && N <= kFoldedAdjointMaxQubits;
+  constexpr bool folded = FOLD && N >= 2 && N <= kFoldedAdjointMaxQubits;   // (QUANTUM = false: the forward alone)
   const int layers = p.n_blocks * p.sel_layers;  // per round
   using AE = AdjointEngine<T, N>;
   const int acc_len = folded ? p.n_rounds * layers * 2 * AE::kFoldSlots : n_rot_all * 8;
