@@ -75,6 +75,48 @@ __device__ __forceinline__ void ry_lane(V2<T> (&a)[R], T c, T s_signed, int lane
     a[r] = __builtin_elementwise_fma(bcast<T>(s_signed), par, bcast<T>(c) * a[r]);
   }
 }
+// RY(theta) on lane bit 4 or 5 without a partner fetch: ONE permlane swap of (re, im) puts the real parts of both pair
+// members into the lanes with the bit clear and their imaginary parts into the lanes with it set (the swap exchanges the
+// set-bit half of its first operand with the clear-bit half of its second).  An RY is real and the same 2 x 2 on both
+// parts, so the gate is in-register and lane-uniform -- lo' = c lo - s hi, hi' = s lo + c hi, the same products as the
+// partner form -- and a second swap puts everything back: 4 instructions in the dependent chain of a layer instead of
+// 10 (two copies, the swap and a select per component for the partner's value).
+template <int Q>
+__device__ __forceinline__ void permlane_swap_bit(uint32_t& x, uint32_t& y) {
+  static_assert(Q == 4 || Q == 5, "row-crossing lane bits");
+  if constexpr (Q == 5) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    x = r[0], y = r[1];
+  } else {
+    const auto r = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+    x = r[0], y = r[1];
+  }
+}
+template <int Q>
+__device__ __forceinline__ void swap_parts(float& x, float& y) {
+  uint32_t ux = __float_as_uint(x), uy = __float_as_uint(y);
+  permlane_swap_bit<Q>(ux, uy);
+  x = __uint_as_float(ux), y = __uint_as_float(uy);
+}
+template <int Q>
+__device__ __forceinline__ void swap_parts(double& x, double& y) {
+  uint32_t xl = (uint32_t)__double2loint(x), xh = (uint32_t)__double2hiint(x);
+  uint32_t yl = (uint32_t)__double2loint(y), yh = (uint32_t)__double2hiint(y);
+  permlane_swap_bit<Q>(xl, yl);
+  permlane_swap_bit<Q>(xh, yh);
+  x = __hiloint2double((int)xh, (int)xl), y = __hiloint2double((int)yh, (int)yl);
+}
+template <int Q, typename T, int R>
+__device__ __forceinline__ void ry_lane_xy(V2<T> (&a)[R], T c, T s) {
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    T lo = a[r].x, hi = a[r].y;
+    swap_parts<Q>(lo, hi);   // (lo member, hi member) of the real parts / of the imaginary parts
+    T nlo = fma(-s, hi, c * lo), nhi = fma(s, lo, c * hi);
+    swap_parts<Q>(nlo, nhi);
+    a[r] = V2<T>{nlo, nhi};
+  }
+}
 // RY(theta) between register pairs (r, r | J)
 template <int J, typename T, int R>
 __device__ __forceinline__ void ry_regs(V2<T> (&a)[R], T c, T s) {
@@ -375,8 +417,8 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
           if constexpr (N > TB) ry_regs<1, T, R>(a, cur.ry[N - 1 - TB].x, cur.ry[N - 1 - TB].y);
           if constexpr (N > TB + 1)
             ry_regs<2, T, R>(a, cur.ry[N > TB + 1 ? N - 2 - TB : 0].x, cur.ry[N > TB + 1 ? N - 2 - TB : 0].y);
-          if constexpr (N > 5) ry_lane<5, T, R>(a, cur.ry[N > 5 ? N - 1 - 5 : 0].x, cur.ry[N > 5 ? N - 1 - 5 : 0].y * pm[5], lane);
-          if constexpr (N > 4) ry_lane<4, T, R>(a, cur.ry[N > 4 ? N - 1 - 4 : 0].x, cur.ry[N > 4 ? N - 1 - 4 : 0].y * pm[4], lane);
+          if constexpr (N > 5) ry_lane_xy<5, T, R>(a, cur.ry[N > 5 ? N - 1 - 5 : 0].x, cur.ry[N > 5 ? N - 1 - 5 : 0].y);
+          if constexpr (N > 4) ry_lane_xy<4, T, R>(a, cur.ry[N > 4 ? N - 1 - 4 : 0].x, cur.ry[N > 4 ? N - 1 - 4 : 0].y);
           if constexpr (N > 3) ry_lane<3, T, R>(a, cur.ry[N > 3 ? N - 1 - 3 : 0].x, cur.ry[N > 3 ? N - 1 - 3 : 0].y * pm[3], lane);
           if constexpr (N > 2) ry_lane<2, T, R>(a, cur.ry[N > 2 ? N - 1 - 2 : 0].x, cur.ry[N > 2 ? N - 1 - 2 : 0].y * pm[2], lane);
           if constexpr (N > 1) ry_lane<1, T, R>(a, cur.ry[N > 1 ? N - 1 - 1 : 0].x, cur.ry[N > 1 ? N - 1 - 1 : 0].y * pm[1], lane);
