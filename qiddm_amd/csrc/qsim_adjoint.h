@@ -29,7 +29,9 @@ __device__ __forceinline__ V2<T> cjfma(V2<T> lam, V2<T> psi, V2<T> acc) {
 // Sum 8 per-lane values over the whole wave; value idx ends up (fully reduced) in the lane whose logical
 // number is < 8 with idx = 4*b0 + 2*b1 + b2 and is added to acc[idx] (LDS, private to the wave).
 // Halving exchange for the first three steps: 7 + 3 exchanged values instead of 48.
-template <typename T>
+// STORE: write the totals instead of adding them (a slot group that is filled once per use needs no zeroing and no
+// read-modify-write round trip)
+template <typename T, bool STORE = false>
 __device__ __forceinline__ void wave_reduce8_into(const T (&v)[8], int lane, int llane, T* acc) {
   const bool b0 = llane & 1, b1 = llane & 2, b2 = llane & 4;
   T w[4];
@@ -50,7 +52,11 @@ __device__ __forceinline__ void wave_reduce8_into(const T (&v)[8], int lane, int
   t += xlane<8>(t, lane);
   t += xlane<16>(t, lane);
   t += xlane<32>(t, lane);
-  if (llane < 8) acc[(b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0)] += t;
+  if (llane < 8) {
+    T* slot = acc + (b0 ? 4 : 0) + (b1 ? 2 : 0) + (b2 ? 1 : 0);
+    if constexpr (STORE) *slot = t;
+    else *slot += t;
+  }
 }
 
 constexpr int kFoldedAdjointMaxQubits = 9;

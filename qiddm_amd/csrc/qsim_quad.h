@@ -59,7 +59,7 @@ struct QuadSmem {
   }
   static constexpr size_t kCzBytes = (size_t)(N - 1) * 256 * 4;
   static constexpr size_t kSlabBytes = (size_t)2 * 4 * R * kWave * 2 * sizeof(T);
-  static constexpr size_t kMiscBytes = (4 * 16 + 16 + 16 + 16) * sizeof(double);
+  static constexpr size_t kMiscBytes = (2 * 4 * 16 + 3 * 4 * 16) * sizeof(double);   // two partial buffers; xs / cs / sn per wave
   __host__ __device__ static size_t bytes(int64_t n_rot) {
     return (ry_bytes(n_rot) + 15) / 16 * 16 + tlo_bytes(n_rot) + thi_bytes(n_rot) + kCzBytes + kSlabBytes + kMiscBytes +
            (size_t)n_rot * sizeof(double);  // staging scratch: the summed RZ angle per (layer, wire)
@@ -258,10 +258,16 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
   uint32_t* s_cz = reinterpret_cast<uint32_t*>(cursor);
   C* s_slab = reinterpret_cast<C*>(reinterpret_cast<unsigned char*>(s_cz) + QS::kCzBytes);
   double* s_part = reinterpret_cast<double*>(reinterpret_cast<unsigned char*>(s_slab) + QS::kSlabBytes);
-  double* s_xs = s_part + 4 * 16;  // [16] angles of the round
-  double* s_cs = s_xs + 16;        // [16] cos(x/2)   (after the read-out: plain <Z_w>)
-  double* s_sn = s_cs + 16;        // [16] sin(x/2)
-  double* s_alpha = s_sn + 16;     // [n_rot] staging only: phi^l_w + omega^{l-1}_w
+  // Barriers: the step needs the two cross-wave sums (linear_down, <Z>) and nothing else outside the layers.  Every wave
+  // combines the four partials ITSELF (lanes < n, redundantly) and keeps its own copy of the round's angles and their
+  // sin / cos -- wave-level ordering only -- and the two sums use separate partial buffers, so neither has to wait for the
+  // other's readers: 2 + layers barriers per step instead of 7 + layers.
+  double* s_part_z = s_part + 4 * 16;  // [4][16] partials of the read-out (s_part: linear_down)
+  const int wv_ = (int)(threadIdx.x >> 6);
+  double* s_xs = s_part_z + 4 * 16 + wv_ * 16;      // [16] angles of the round, this wave's copy
+  double* s_cs = s_part_z + 2 * 4 * 16 + wv_ * 16;  // [16] cos(x/2)   (after the read-out: plain <Z_w>)
+  double* s_sn = s_part_z + 3 * 4 * 16 + wv_ * 16;  // [16] sin(x/2)
+  double* s_alpha = s_part_z + 4 * 4 * 16;          // [n_rot] staging only: phi^l_w + omega^{l-1}_w
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -310,7 +316,12 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
   T pm[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) pm[q] = ((kbase >> q) & 1u) ? (T)1 : (T)-1;  // (bits 6, 7 unused when TB == 6)
-  const double bd_mine = (bd && tid < N) ? bd[tid] : 0.0;
+  const double bd_mine = (bd && lane < N) ? bd[lane] : 0.0;
+  auto wave_sync = [&]() {   // LDS hand-over inside the wavefront
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
   __syncthreads();
   if (stamp) d.stamps[1] = __builtin_amdgcn_s_memtime();
 
@@ -335,40 +346,38 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
 #pragma unroll
         for (int j = 0; j < N; ++j) acc[j] = fma(xr[i], wdr[i][j], acc[j]);  // padded slots hold zeros
       }
-      __syncthreads();  // s_part free (previous readers done)
-      if (lane < 16) s_part[wv * 16 + lane] = 0.0;
+      // (s_part is free: its last readers ran before the barrier of the previous step's read-out)
       {
         double v8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v8[j] = acc[j];
-        wave_reduce8_into<double>(v8, lane, llane, s_part + wv * 16);
+        wave_reduce8_into<double, true>(v8, lane, llane, s_part + wv * 16);
         if constexpr (N > 8) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v8[j] = acc[8 + j];
-          wave_reduce8_into<double>(v8, lane, llane, s_part + wv * 16 + 8);
+          wave_reduce8_into<double, true>(v8, lane, llane, s_part + wv * 16 + 8);
         }
       }
       __syncthreads();
-      if (tid < N) {
+      if (lane < N) {
         // wave_reduce8_into leaves value idx in slot idx of its 8-slot group
-        const double h = s_part[tid] + s_part[16 + tid] + s_part[32 + tid] + s_part[48 + tid] + bd_mine;
-        s_xs[tid] = h * p.enc_scale;
+        const double h = s_part[lane] + s_part[16 + lane] + s_part[32 + lane] + s_part[48 + lane] + bd_mine;
+        s_xs[lane] = h * p.enc_scale;
       }
       if (stamp && step == 0) d.stamps[2] = __builtin_amdgcn_s_memtime();
 
       // ---- circuit rounds ------------------------------------------------------------------------------
       for (int round = 0; round < p.n_rounds; ++round) {
-        __syncthreads();  // s_xs ready
-        if (tid < N) {
+        if (lane < N) {   // the lane that wrote s_xs[lane] (this wave's copy)
           double s, c;
-          table_sincos<T>(0.5 * s_xs[tid], &s, &c);
-          s_cs[tid] = c;
-          s_sn[tid] = s;
+          table_sincos<T>(0.5 * s_xs[lane], &s, &c);
+          s_cs[lane] = c;
+          s_sn[lane] = s;
         }
         // first layer's data while the angles' sin/cos settle
         QuadLayerData<T, N> cur;
         cur.load(s_ry, s_tlo, s_thi, s_cz, round * layers_per_round, -1, tid);
-        __syncthreads();
+        wave_sync();
         // per-sample RZ diagonal of this thread's amplitudes
         C dx[R];
         {
@@ -466,30 +475,29 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
 #pragma unroll
           for (int w = 0; w < N; ++w) ez[w] += ((k >> (N - 1 - w)) & 1u) ? -pr : pr;
         }
-        __syncthreads();  // s_part free
-        if (lane < 16) s_part[wv * 16 + lane] = 0.0;
+        wave_sync();   // (this wave's readers of s_cs / s_sn are done)
         {
           double v8[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) v8[j] = (double)ez[j];
-          wave_reduce8_into<double>(v8, lane, llane, s_part + wv * 16);
+          wave_reduce8_into<double, true>(v8, lane, llane, s_part_z + wv * 16);
           if constexpr (N > 8) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v8[j] = (double)ez[8 + j];
-            wave_reduce8_into<double>(v8, lane, llane, s_part + wv * 16 + 8);
+            wave_reduce8_into<double, true>(v8, lane, llane, s_part_z + wv * 16 + 8);
           }
         }
         __syncthreads();
-        if (tid < N) {
+        if (lane < N) {
           // TB == 6: every wave summed the whole (replicated) state -- take wave 0's
           // (below 6 qubits the wave's 64 lanes summed 2^(6-TB) copies)
-          const double e = TB == 8 ? s_part[tid] + s_part[16 + tid] + s_part[32 + tid] + s_part[48 + tid]
-                                   : s_part[tid] * (1.0 / (double)(1 << (TB < 6 ? 6 - TB : 0)));
-          s_xs[tid] = e * p.enc_scale;  // next round's angles
-          s_cs[tid] = e;                // plain <Z_w> for linear_up (s_cs is rebuilt next round)
+          const double e = TB == 8 ? s_part_z[lane] + s_part_z[16 + lane] + s_part_z[32 + lane] + s_part_z[48 + lane]
+                                   : s_part_z[lane] * (1.0 / (double)(1 << (TB < 6 ? 6 - TB : 0)));
+          s_xs[lane] = e * p.enc_scale;  // next round's angles
+          s_cs[lane] = e;                // plain <Z_w> for linear_up (s_cs is rebuilt next round)
         }
       }
-      __syncthreads();
+      wave_sync();
       if (stamp && step == 0) d.stamps[3] = __builtin_amdgcn_s_memtime();
       double ev[N];
 #pragma unroll
