@@ -102,6 +102,24 @@ __device__ __forceinline__ void sincos_for_f32_table(double x, double* s, double
   *s = (q & 2) ? -ss : ss;
   *c = ((q + 1) & 2) ? -cc : cc;
 }
+// sin/cos of a float64 angle for the float32 engine's DATA angles (one per qubit, round and sample, on the critical path of
+// a sampling step): range reduction in double (exact for any angle the nets produce), the fdlibm k_sinf / k_cosf
+// polynomials in float -- ~1 ulp of float, a third of the cycles of the all-double evaluation above
+__device__ __forceinline__ void data_sincos_f32(double x, float* s, float* c) {
+  const double kd = rint(x * 0.63661977236758134308);
+  double rd = fma(-kd, 1.57079632679489655800e+00, x);
+  rd = fma(-kd, 6.12323399573676603587e-17, rd);
+  const float r = (float)rd;
+  const float z = r * r;
+  const float sp = fmaf(r * z, fmaf(z, fmaf(z, fmaf(z, 2.7183114939898219064e-6f, -1.98393348360966317347e-4f),
+                                          8.3333293858894631756e-3f), -1.66666666416265235595e-1f), r);
+  const float cp = fmaf(z, fmaf(z, fmaf(z, fmaf(z, 2.43904487962774090654e-5f, -1.38867637746099294692e-3f),
+                                       4.16666233237390631894e-2f), -4.99999997251031003120e-1f), 1.0f);
+  const int q = (int)(long long)kd & 3;
+  const float ss = (q & 1) ? cp : sp, cc = (q & 1) ? sp : cp;
+  *s = (q & 2) ? -ss : ss;
+  *c = ((q + 1) & 2) ? -cc : cc;
+}
 template <typename T>
 __device__ __forceinline__ void table_sincos(double x, double* s, double* c) {
   if constexpr (sizeof(T) == 4) sincos_for_f32_table(x, s, c);

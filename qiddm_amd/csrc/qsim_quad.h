@@ -369,10 +369,17 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
       // ---- circuit rounds ------------------------------------------------------------------------------
       for (int round = 0; round < p.n_rounds; ++round) {
         if (lane < N) {   // the lane that wrote s_xs[lane] (this wave's copy)
-          double s, c;
-          table_sincos<T>(0.5 * s_xs[lane], &s, &c);
-          s_cs[lane] = c;
-          s_sn[lane] = s;
+          if constexpr (sizeof(T) == 4) {
+            float s, c;
+            data_sincos_f32(0.5 * s_xs[lane], &s, &c);
+            s_cs[lane] = (double)c;
+            s_sn[lane] = (double)s;
+          } else {
+            double s, c;
+            sincos(0.5 * s_xs[lane], &s, &c);
+            s_cs[lane] = c;
+            s_sn[lane] = s;
+          }
         }
         // first layer's data while the angles' sin/cos settle
         QuadLayerData<T, N> cur;
@@ -402,12 +409,35 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
             }
           }
         }
+        // The round's first layer acts on |0..0>: its diagonal (data angles included) is a global phase and its RYs make a
+        // real product state, amplitude k = prod_q (bit q of k ? sin : cos)(theta_q / 2).  Generated per thread -- no
+        // cross-lane move, no exchange, no barrier -- instead of simulated: one layer less per round.
         C a[R];
+        {
+          T fe = 1, fo = 1;
 #pragma unroll
-        for (int r = 0; r < R; ++r) a[r] = C{(T)0, (T)0};
-        a[0] = C{kbase == 0 ? (T)1 : (T)0, (T)0};
+          for (int q = 0; q < TB; ++q) {
+            const C cs = cur.ry[N - 1 - q];
+            const T f = ((kbase >> q) & 1u) ? cs.y : cs.x;
+            if (q & 1) fo *= f;
+            else fe *= f;
+          }
+          const T f = fe * fo;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            T g = f;
+#pragma unroll
+            for (int j = 0; j < N - TB; ++j) {
+              const C cs = cur.ry[N - 1 - (TB + j)];
+              g *= ((r >> j) & 1) ? cs.y : cs.x;
+            }
+            a[r] = C{g, (T)0};
+          }
+          const int l_next = round * layers_per_round + 1;
+          cur.load(s_ry, s_tlo, s_thi, s_cz, l_next < n_layers_all ? l_next : 0, 0, tid);
+        }
 
-        for (int li = 0; li < layers_per_round; ++li) {
+        for (int li = 1; li < layers_per_round; ++li) {
           const int s = li % p.sel_layers;
           // ---- everything diagonal in front of this layer's RYs: one complex multiply per amplitude ----
 #pragma unroll
@@ -476,23 +506,27 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
           for (int w = 0; w < N; ++w) ez[w] += ((k >> (N - 1 - w)) & 1u) ? -pr : pr;
         }
         wave_sync();   // (this wave's readers of s_cs / s_sn are done)
+        // (summed over the wavefront in the engine's own precision -- the 64 terms are |amplitude|^2 of that precision --
+        //  and over the four waves in double)
+        T* s_pz = reinterpret_cast<T*>(s_part_z);
         {
-          double v8[8];
+          T v8[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v8[j] = (double)ez[j];
-          wave_reduce8_into<double, true>(v8, lane, llane, s_part_z + wv * 16);
+          for (int j = 0; j < 8; ++j) v8[j] = ez[j];
+          wave_reduce8_into<T, true>(v8, lane, llane, s_pz + wv * 16);
           if constexpr (N > 8) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v8[j] = (double)ez[8 + j];
-            wave_reduce8_into<double, true>(v8, lane, llane, s_part_z + wv * 16 + 8);
+            for (int j = 0; j < 8; ++j) v8[j] = ez[8 + j];
+            wave_reduce8_into<T, true>(v8, lane, llane, s_pz + wv * 16 + 8);
           }
         }
         __syncthreads();
         if (lane < N) {
           // TB == 6: every wave summed the whole (replicated) state -- take wave 0's
           // (below 6 qubits the wave's 64 lanes summed 2^(6-TB) copies)
-          const double e = TB == 8 ? s_part_z[lane] + s_part_z[16 + lane] + s_part_z[32 + lane] + s_part_z[48 + lane]
-                                   : s_part_z[lane] * (1.0 / (double)(1 << (TB < 6 ? 6 - TB : 0)));
+          const double e = TB == 8 ? (double)s_pz[lane] + (double)s_pz[16 + lane] + (double)s_pz[32 + lane] +
+                                         (double)s_pz[48 + lane]
+                                   : (double)s_pz[lane] * (1.0 / (double)(1 << (TB < 6 ? 6 - TB : 0)));
           s_xs[lane] = e * p.enc_scale;  // next round's angles
           s_cs[lane] = e;                // plain <Z_w> for linear_up (s_cs is rebuilt next round)
         }
