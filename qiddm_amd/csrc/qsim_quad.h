@@ -444,7 +444,11 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
           for (int r = 0; r < R; ++r) {
             C ph = cur.tlo;
             if constexpr (R > 1) ph = cmul2<T>(cur.thi[r], ph, times_i<T>(ph));
-            if (s == 0) ph = cmul2<T>(dx[r], ph, times_i<T>(ph));  // block start: data re-upload
+            if (s == 0) {  // block start: data re-upload.  A real (scalar) branch: if-converted, the multiply ran in
+                           // every layer and a select threw it away in all but the block starts
+              asm volatile("" ::: "memory");
+              ph = cmul2<T>(dx[r], ph, times_i<T>(ph));
+            }
             C v = cmul2<T>(ph, a[r], times_i<T>(a[r]));
             if constexpr (R > 1) {
               const uint32_t sb = ((cur.cz >> r) & 1u) << 31;  // CZ ring of the previous layer
@@ -471,21 +475,27 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
             xbuf_parity ^= 1;
 #pragma unroll
             for (int r = 0; r < R; ++r) buf[(wv * R + r) * kWave + lane] = a[r];
-            // next layer's data: in flight across the barrier
+            C own[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) own[r] = bcast<T>(k0) * a[r];   // this wave's term: before the barrier
+            __syncthreads();   // (only the slab write is waited for in front of it)
+            C p1[R], p2[R], p3[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+              p1[r] = buf[((wv ^ 1) * R + r) * kWave + lane];
+              p2[r] = buf[((wv ^ 2) * R + r) * kWave + lane];
+              p3[r] = buf[((wv ^ 3) * R + r) * kWave + lane];
+            }
+            // next layer's data: read BEHIND the partners' amplitudes (LDS returns in order), off the critical path
             {
               const int l_next = round * layers_per_round + li + 1;
               cur.load(s_ry, s_tlo, s_thi, s_cz, l_next < n_layers_all ? l_next : 0, s % (N - 1), tid);
             }
-            __syncthreads();
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-              const C p1 = buf[((wv ^ 1) * R + r) * kWave + lane];
-              const C p2 = buf[((wv ^ 2) * R + r) * kWave + lane];
-              const C p3 = buf[((wv ^ 3) * R + r) * kWave + lane];
-              C o = bcast<T>(k0) * a[r];
-              o = __builtin_elementwise_fma(bcast<T>(k1), p1, o);
-              o = __builtin_elementwise_fma(bcast<T>(k2), p2, o);
-              a[r] = __builtin_elementwise_fma(bcast<T>(k3), p3, o);
+            for (int r = 0; r < R; ++r) {   // two chains of depth two behind the reads instead of one of depth three
+              const C o = __builtin_elementwise_fma(bcast<T>(k1), p1[r], own[r]);
+              const C t = __builtin_elementwise_fma(bcast<T>(k3), p3[r], bcast<T>(k2) * p2[r]);
+              a[r] = o + t;
             }
           } else {
             // the whole state is in this wave: nothing to exchange, only the next layer's data to fetch
