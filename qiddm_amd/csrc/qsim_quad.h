@@ -140,6 +140,22 @@ struct QuadLayerData {
   C thi[R];    // register-bit phases (n > 8)
   uint32_t cz; // parity bits of the PREVIOUS layer's ring (n > 8)
 
+  // this thread's phase alone (the first thing a layer needs)
+  __device__ __forceinline__ static C load_tlo(const C* s_tlo, int layer, int tid) {
+    constexpr int TL = 1 << quad_thread_bits<N>();
+    return s_tlo[layer * TL + (quad_thread_bits<N>() < 6 ? (int)quad_kbase<N>(0, logical_lane(tid & 63)) : (tid & (TL - 1)))];
+  }
+  // everything but tlo
+  __device__ __forceinline__ void load_rest(const C* s_ry, const C* s_thi, const uint32_t* s_cz, int layer,
+                                            int prev_range, int tid) {
+#pragma unroll
+    for (int w = 0; w < N; ++w) ry[w] = s_ry[layer * N + w];
+    if constexpr (R > 1) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) thi[r] = s_thi[layer * R + r];
+      cz = prev_range >= 0 ? s_cz[prev_range * 256 + tid] : 0u;
+    }
+  }
   __device__ __forceinline__ void load(const C* s_ry, const C* s_tlo, const C* s_thi, const uint32_t* s_cz, int layer,
                                        int prev_range, int tid) {
 #pragma unroll
@@ -478,7 +494,12 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
             C own[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) own[r] = bcast<T>(k0) * a[r];   // this wave's term: before the barrier
-            __syncthreads();   // (only the slab write is waited for in front of it)
+            // the next layer's phase -- the first thing it needs -- is read in front of the barrier (one read, back long
+            // before the slab write is), the rest of its tables behind the partners' amplitudes
+            const int l_next = round * layers_per_round + li + 1;
+            const int l_load = l_next < n_layers_all ? l_next : 0;
+            const C tlo_next = QuadLayerData<T, N>::load_tlo(s_tlo, l_load, tid);
+            __syncthreads();
             C p1[R], p2[R], p3[R];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -486,11 +507,8 @@ __global__ __launch_bounds__(256) void dense_quad_kernel(
               p2[r] = buf[((wv ^ 2) * R + r) * kWave + lane];
               p3[r] = buf[((wv ^ 3) * R + r) * kWave + lane];
             }
-            // next layer's data: read BEHIND the partners' amplitudes (LDS returns in order), off the critical path
-            {
-              const int l_next = round * layers_per_round + li + 1;
-              cur.load(s_ry, s_tlo, s_thi, s_cz, l_next < n_layers_all ? l_next : 0, s % (N - 1), tid);
-            }
+            cur.load_rest(s_ry, s_thi, s_cz, l_load, s % (N - 1), tid);
+            cur.tlo = tlo_next;
 #pragma unroll
             for (int r = 0; r < R; ++r) {   // two chains of depth two behind the reads instead of one of depth three
               const C o = __builtin_elementwise_fma(bcast<T>(k1), p1[r], own[r]);
