@@ -560,9 +560,11 @@ def main():
         g_per_sample = circ.gate_count()
         alg_bytes = circ.algorithmic_bytes_per_sample("f32") * args.batch * kspl   # per launch
         hbm_eq = alg_bytes / (kern_us * 1e-6) / 1e9
-        # what the kernel actually executes (folded tables): per amplitude and layer one complex multiply (6 flop)
-        # + n real RY updates (6 flop each), plus <Z> and the two linears
-        flop = QDEPTH * (1 << N_QUBITS) * (6 + 6 * N_QUBITS) + 2 * N_QUBITS * (1 << N_QUBITS) + 2 * 2 * IMG * IMG * N_QUBITS
+        # what the kernel actually executes (folded tables): per amplitude and SIMULATED layer one complex multiply
+        # (6 flop) + n real RY updates (6 flop each); the round's first layer acts on |0..0> and is generated as a product
+        # state (n multiplies per amplitude); plus <Z> and the two linears
+        flop = ((QDEPTH - 1) * (1 << N_QUBITS) * (6 + 6 * N_QUBITS) + N_QUBITS * (1 << N_QUBITS)
+                + 2 * N_QUBITS * (1 << N_QUBITS) + 2 * 2 * IMG * IMG * N_QUBITS)
         valu_tf = flop * args.batch * kspl / (kern_us * 1e-6) / 1e12
         io_bytes = (kspl + 1) * args.batch * IMG * IMG * 8        # first image in + one image out per step (exact)
         result = {
