@@ -481,12 +481,43 @@ struct Engine {
     }
   }
   // all layers of one round on the folded tables; `first_layer` = index of the round's first layer
+  // A round that starts from |0..0> (every encoding but the amplitude embedding): the first layer's diagonal -- data
+  // angles included -- is a global phase and its RYs make a real product state, amplitude k = prod_q (bit q of k ? sin :
+  // cos)(theta_q / 2).  Generated per lane (n multiplies, no cross-lane move) instead of simulated; `ry` = the layer's
+  // (cos, sin) pairs by wire.
+  __device__ __forceinline__ void product_state(const C* ry, C (&a)[R]) const {
+    T fe = 1, fo = 1;
+#pragma unroll
+    for (int q = 0; q < LB; ++q) {
+      const C cs = ry[N - 1 - q];
+      const T f = ((sub >> q) & 1) ? cs.y : cs.x;
+      if (q & 1) fo *= f;
+      else fe *= f;
+    }
+    const T f = fe * fo;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      T g = f;
+#pragma unroll
+      for (int j = 0; j < N - LB; ++j) {
+        const C cs = ry[N - 1 - (LB + j)];
+        g *= ((r >> j) & 1) ? cs.y : cs.x;
+      }
+      a[r] = C{g, (T)0};
+    }
+  }
   __device__ __forceinline__ void folded_round(const KScalars& p, C (&a)[R], const C (&dx)[R], int first_layer,
                                                int n_layers_all) const {
     const int layers = p.n_blocks * p.sel_layers;
     FoldedLayer cur;
     load_folded(first_layer, -1, cur);
-    for (int li = 0; li < layers; ++li) {
+    int li0 = 0;
+    if (p.encoding != 1) {   // the caller's |0..0> is replaced by the state behind the first layer
+      product_state(cur.ry, a);
+      load_folded(first_layer + 1 < n_layers_all ? first_layer + 1 : 0, N > 1 ? 0 : -1, cur);
+      li0 = 1;
+    }
+    for (int li = li0; li < layers; ++li) {
       const int s = li % p.sel_layers;
       FoldedLayer nxt;
       {
@@ -544,7 +575,16 @@ struct Engine {
   }
   __device__ __forceinline__ void folded_round_u(const KScalars& p, C (&a)[R], const C (&dx)[R], int first_layer) const {
     const int layers = p.n_blocks * p.sel_layers;
-    for (int li = 0; li < layers; ++li) {
+    int li0 = 0;
+    if (p.encoding != 1) {   // (see folded_round)
+      const C* __restrict__ b0 = reinterpret_cast<const C*>(s_gates + (size_t)first_layer * S::kFoldStride);
+      C ry0[N];
+#pragma unroll
+      for (int w = 0; w < N; ++w) ry0[w] = C{uni(b0[w].x), uni(b0[w].y)};
+      product_state(ry0, a);
+      li0 = 1;
+    }
+    for (int li = li0; li < layers; ++li) {
       const int s = li % p.sel_layers;
       const C* __restrict__ base = reinterpret_cast<const C*>(s_gates + (size_t)(first_layer + li) * S::kFoldStride);
       const C tlo = base[N + sub];
