@@ -413,6 +413,25 @@ def conv1x1_forward(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor
 _train_workspaces = {}
 
 
+_SCHEDULES_F32 = {}
+
+
+def _schedule_f32(schedule: torch.Tensor, device) -> torch.Tensor:
+    """The noising schedule as the flat float32 device tensor the step reads.  The schedule of a (tau, decay) pair is
+    one cached tensor (noise._schedule), so its converted copy is cached too: converting it per step is an 11-element
+    launch in front of every training step (5 us of the recorded C2 step)."""
+    if schedule.dtype == torch.float32 and schedule.device == torch.device(device) and schedule.is_contiguous():
+        return schedule.reshape(-1)
+    key = (schedule.data_ptr(), schedule._version, schedule.dtype, tuple(schedule.shape), str(device))
+    hit = _SCHEDULES_F32.get(key)
+    if hit is None or hit[0] is not schedule:
+        if len(_SCHEDULES_F32) > 64:
+            _SCHEDULES_F32.clear()
+        hit = (schedule, schedule.to(device=device, dtype=torch.float32).reshape(-1).contiguous())
+        _SCHEDULES_F32[key] = hit
+    return hit[1]
+
+
 def train_step(circ: Circuit, x: torch.Tensor, noise: torch.Tensor, schedule: torch.Tensor, goal: str,
                w_down, b_down, angles, w_up, b_up, train_quantum: bool, want_recon: bool = False,
                want_elem_loss: bool = False, precision: str | None = None, rng_state: torch.Tensor | None = None):
@@ -440,7 +459,7 @@ def train_step(circ: Circuit, x: torch.Tensor, noise: torch.Tensor, schedule: to
             raise ValueError("with rng_state the noise buffer is an output: pass a float32 device tensor")
         if rng_state.dtype != torch.int64 or rng_state.numel() != 2 or not rng_state.is_cuda:
             raise ValueError("rng_state must be a (2,) int64 device tensor {seed, offset}")
-    sch = schedule.to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+    sch = _schedule_f32(schedule, device)
     wd, bd, wu, bu, ang = (_as_f64(t, device) for t in (w_down, b_down, w_up, b_up, angles))
     if tuple(ang.shape) != circ.angles_shape:
         raise ValueError(f"angles must have shape {circ.angles_shape}; got {tuple(ang.shape)}")
