@@ -612,7 +612,9 @@ def main():
                                            "HBM simulator would move. Not a roofline fraction: the slab never leaves "
                                            "the registers"},
                 "note": "latency-bound at batch 256: one sample per CU, one wavefront per SIMD, every layer a dependent "
-                        "chain of cross-lane moves",
+                        "chain of cross-lane moves. All 14 layers of every step are computed: the first one acts on "
+                        "|0..0> and its result (a real product state) is generated per amplitude instead of simulated "
+                        "gate by gate -- exact for every input and weight; executed_flop counts it as n multiplies",
             },
         }
         if train:
