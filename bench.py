@@ -119,7 +119,7 @@ class Runner:
     last image in place) and then refreshes the static input once.  Graphs are recorded per distinct launch plan,
     ahead of the timed region (`prepare`)."""
 
-    def __init__(self, diff, x0, use_graph, spl, launches_per_graph=5):
+    def __init__(self, diff, x0, use_graph, spl, launches_per_graph=8):
         self.diff, self.x, self.use_graph, self.spl, self.lpg = diff, x0.clone(), use_graph, spl, launches_per_graph
         self.graphs = {}
         if use_graph:
