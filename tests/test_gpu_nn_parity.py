@@ -211,7 +211,12 @@ def test_diffusion_training_step_on_device():
 
 @pytest.mark.parametrize("precision,tol", [("f32", 5e-5), ("f64", 1e-10)])
 @pytest.mark.parametrize("n,N,L,S,P", [(8, 1, 1, 14, 784), (8, 2, 6, 2, 784), (4, 1, 2, 2, 64), (2, 2, 1, 3, 10),
-                                       (6, 2, 14, 2, 784), (10, 1, 3, 2, 100)])
+                                       (6, 2, 14, 2, 784), (10, 1, 3, 2, 100),
+                                       # every thread-bit layout of the four-wave sampler: spare lane bits (3, 5), one wave
+                                       # per replica (7), one and two register bits (9, 10); a one-layer round (generated
+                                       # product state measured directly)
+                                       (3, 1, 2, 2, 9), (5, 2, 1, 4, 25), (7, 1, 3, 1, 49), (9, 2, 2, 2, 81),
+                                       (8, 2, 1, 1, 64)])
 def test_dense_forward_kernel(n, N, L, S, P, precision, tol):
     """qiddm_dense_forward: linear_down -> rounds -> linear_up in one launch, both post modes,
     including the sub-wave layouts (n < 6: several samples per wavefront) and a ragged batch."""
