@@ -420,8 +420,14 @@ __global__ __launch_bounds__(kGradWaves* kWave) void train_weight_grads_kernel(
     const double* __restrict__ gxr, double* __restrict__ partials, double* __restrict__ loss_partials,
     double* __restrict__ recon, double* __restrict__ elem, int64_t batch, const TrainScalars d) {
   __shared__ double s_red[kGradWaves - 1][2 * N + 2][kWave];
+  // the <Z> and input-gradient rows of the sample a wave is on (T x n doubles each): fetched with ONE coalesced load per
+  // sample and read back as LDS broadcasts -- read row by row from global memory they are wave-uniform scalar loads, a
+  // dependent L2 round trip per noise level (the wave sat 9.6 us on 565 instructions)
+  constexpr int kRowCap = 32 * N;   // T <= 32 levels staged; beyond that the rows are read in place
+  __shared__ double s_rows[kGradWaves][2][kRowCap];
   const int P = d.pixels;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+  const bool staged = d.T * N <= kRowCap;
   const int pix = blockIdx.x * kWave + lane;
   const bool pvalid = pix < P;
   const int pc = pvalid ? pix : 0;
@@ -441,32 +447,48 @@ __global__ __launch_bounds__(kGradWaves* kWave) void train_weight_grads_kernel(
   for (int64_t b = b0 + wave; b < b1; b += kGradWaves) {  // the chunk's samples are dealt to the waves
     const double xv = x[b * d.x_ld + pc];
     const float nz = noise[b * d.noise_ld + pc];
-    double clean = blend_noise(xv, nz, sched[0]);
-    for (int t = 1; t <= d.T; ++t) {
-      const double noisy = blend_noise(xv, nz, sched[t]);
-      const int64_t row = b * d.T + (t - 1);
-      const double* __restrict__ evp = ev + row * N;
-      double o = buv;
-#pragma unroll
-      for (int j = 0; j < N; ++j) o = fma(evp[j], wur[j], o);
-      const double r = residual(d.goal, o, noisy, clean);
-      const double g = d.grad_scale * r;
-      loss = fma(r, r, loss);
-      acc_bu += g;
-#pragma unroll
-      for (int j = 0; j < N; ++j) acc_wu[j] = fma(g, evp[j], acc_wu[j]);
-      if (quantum) {
-        const double* __restrict__ gp = gxr + row * N;
-#pragma unroll
-        for (int j = 0; j < N; ++j) acc_wd[j] = fma(gp[j], noisy, acc_wd[j]);
+    if (staged) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the previous sample's readers are done
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < d.T * N; i += kWave) {
+        s_rows[wave][0][i] = ev[b * d.T * N + i];
+        s_rows[wave][1][i] = quantum ? gxr[b * d.T * N + i] : 0.0;
       }
-      if (pvalid) {
-        if (d.want_recon)
-          recon[row * P + pix] = d.goal == 0 ? o : fmin(fmax(noisy - (o - 0.5) * 0.1, 0.0), 1.0);
-        if (d.want_elem) elem[row * P + pix] = r * r;
-      }
-      clean = noisy;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    // one loop per source of the rows (two instantiations: the LDS one reads with ds_read broadcasts, not flat loads)
+    auto levels = [&](const double* __restrict__ ev_rows, const double* __restrict__ gx_rows) {
+      double clean = blend_noise(xv, nz, sched[0]);
+      for (int t = 1; t <= d.T; ++t) {
+        const double noisy = blend_noise(xv, nz, sched[t]);
+        const int64_t row = b * d.T + (t - 1);
+        const double* __restrict__ evp = ev_rows + (t - 1) * N;
+        double o = buv;
+#pragma unroll
+        for (int j = 0; j < N; ++j) o = fma(evp[j], wur[j], o);
+        const double r = residual(d.goal, o, noisy, clean);
+        const double g = d.grad_scale * r;
+        loss = fma(r, r, loss);
+        acc_bu += g;
+#pragma unroll
+        for (int j = 0; j < N; ++j) acc_wu[j] = fma(g, evp[j], acc_wu[j]);
+        if (quantum) {
+          const double* __restrict__ gp = gx_rows + (t - 1) * N;
+#pragma unroll
+          for (int j = 0; j < N; ++j) acc_wd[j] = fma(gp[j], noisy, acc_wd[j]);
+        }
+        if (pvalid) {
+          if (d.want_recon)
+            recon[row * P + pix] = d.goal == 0 ? o : fmin(fmax(noisy - (o - 0.5) * 0.1, 0.0), 1.0);
+          if (d.want_elem) elem[row * P + pix] = r * r;
+        }
+        clean = noisy;
+      }
+    };
+    if (staged) levels(&s_rows[wave][0][0], &s_rows[wave][1][0]);
+    else levels(ev + b * d.T * N, gxr + b * d.T * N);
   }
   // waves 1.. hand their sums to wave 0 (fixed order)
   if (wave > 0) {
