@@ -49,6 +49,42 @@ def imsave_gray_levels(img: np.ndarray) -> np.ndarray:
     return _GRAY_LUT8[np.clip(np.floor(x * 256.0), 0, 255).astype(np.int64)]
 
 
+def imsave_gray_index(img: np.ndarray) -> np.ndarray:
+    """The colour-map index (0..255) behind ``imsave_gray_levels``: the quantity a numerical difference moves by one
+    step; the byte table then shows that step as 0, 1 or 2 grey levels (tests/test_oracle_reference_runs.py)."""
+    img = np.asarray(img, dtype=np.float64)
+    lo, hi = img.min(), img.max()
+    x = (img - lo) / (hi - lo) if hi > lo else np.zeros_like(img)
+    return np.clip(np.floor(x * 256.0), 0, 255).astype(np.int64)
+
+
+# for every grey level a PNG can hold: the colour indices that produce it (one, or two where the byte table
+# truncates the next entry down onto it; none for the 24 levels the table skips)
+_INDEX_LO = np.full(256, 10 ** 6, dtype=np.int64)
+_INDEX_HI = np.full(256, -(10 ** 6), dtype=np.int64)
+for _i, _l in enumerate(_GRAY_LUT8):
+    _INDEX_LO[_l] = min(_INDEX_LO[_l], _i)
+    _INDEX_HI[_l] = max(_INDEX_HI[_l], _i)
+
+
+def index_steps_from_levels(index: np.ndarray, ref_levels: np.ndarray) -> np.ndarray:
+    """Distance, in colour-index steps, from ``index`` to the nearest index that the byte table maps to the saved
+    grey level ``ref_levels`` (huge where the level cannot come out of the table at all)."""
+    lo, hi = _INDEX_LO[ref_levels], _INDEX_HI[ref_levels]
+    return np.where(index < lo, lo - index, np.where(index > hi, index - hi, 0))
+
+
+def indices_from_images(stack: torch.Tensor) -> np.ndarray:
+    """``levels_from_images`` before the byte table: ``(batch, iters, H, W)`` colour indices."""
+    out = torch.clamp(torch.clamp(stack.double().cpu(), 0.0, 1.0) * 255.0, 0.0, 255.0).numpy()
+    it, b = out.shape[:2]
+    ix = np.zeros((b, it) + out.shape[3:], dtype=np.int64)
+    for i in range(b):
+        for s in range(it):
+            ix[i, s] = imsave_gray_index(out[s, i, 0])
+    return ix
+
+
 def qiddm_pl_forward(x_img, weights1, up_w, up_b, pca=opca.pca_fit_transform):
     """``QIDDM_PL_noise.forward`` (``nn/qdense.py:1424-1448``) including the per-call PCA fit."""
     b = x_img.shape[0]

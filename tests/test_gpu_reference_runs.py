@@ -52,7 +52,11 @@ def test_hip_sampling_reproduces_reference_pngs(folder, precision, device_pca):
     assert gen.shape == (6, 10, 1, 28, 28)
     lv = rr.levels_from_images(gen / 255.0)
     err = np.abs(lv - steps[folder])
-    # one step of the 256-entry colour index; matplotlib's byte table skips 24 levels (33 -> 32, 34 -> 34 ...), so one
-    # index step can show as two grey levels.  complex128 kernels: same bound as the oracle itself.
+    # The bound is ONE step of the 256-entry colour index, in both precisions.  matplotlib's byte table truncates 24
+    # entries, so one index step can show as two grey levels -- enumerated in
+    # tests/test_oracle_reference_runs.py::test_byte_table_one_index_step_is_at_most_two_grey_levels -- which is all the
+    # level bound below says; the index distance is the derived form.
+    ix = rr.indices_from_images(gen / 255.0)
+    assert rr.index_steps_from_levels(ix, steps[folder]).max() <= 1, (folder, precision)
     assert err.max() <= (2 if precision == "f32" else 1), (folder, precision, err.max())
     assert (err == 0).mean() > (0.995 if precision == "f32" else 0.999), (err == 0).mean()

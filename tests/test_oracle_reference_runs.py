@@ -101,3 +101,57 @@ def test_ry_sign_is_unobservable_in_this_family():
     a = oc.run_circuit(spec, x, w)
     b = oc.run_circuit(spec, x, w * torch.tensor([1.0, -1.0, 1.0], dtype=w.dtype))
     assert torch.allclose(a, b, atol=1e-12)
+
+
+# ---- where the "two grey levels" of the float32 GPU bound comes from (tests/test_gpu_reference_runs.py) ----------------
+def test_byte_table_one_index_step_is_at_most_two_grey_levels():
+    """matplotlib writes ``(linspace(0, 1, 256) * 255).astype(uint8)``: a truncation.  Enumerated: every entry is its
+    own index or one below it; exactly 24 entries are one below; one colour-index step therefore shows as 0, 1 or 2
+    grey levels, and 2 happens exactly on the steps out of a truncated entry into an exact one."""
+    lut = rr._GRAY_LUT8
+    idx = np.arange(256)
+    assert lut.shape == (256,) and lut[0] == 0 and lut[255] == 255
+    assert set(np.unique(idx - lut)) == {0, 1}
+    truncated = idx[lut == idx - 1]
+    assert len(truncated) == 24
+    step = np.diff(lut)                                        # grey levels per colour-index step i -> i + 1
+    assert step.min() == 0 and step.max() == 2
+    two = idx[:-1][step == 2]
+    assert set(two) == {i for i in truncated if i + 1 not in set(truncated)} and len(two) > 0
+    zero = idx[:-1][step == 0]
+    assert set(zero) == {i for i in idx[:-1] if i not in set(truncated) and i + 1 in set(truncated)}
+    # the table is monotone, so k index steps are at most 2k levels; and two steps never add up to more than 3
+    assert (lut[2:] - lut[:-2]).max() == 3
+    # 24 grey levels can never appear in a saved PNG; the fixtures indeed avoid them
+    skipped = sorted(set(range(256)) - set(lut.tolist()))
+    assert len(skipped) == 24
+    steps, _ = _load()
+    assert not np.isin(steps, skipped).any()
+
+
+def test_index_distance_is_the_derived_form_of_the_level_bound():
+    """|index - index'| <= 1  =>  |level - level'| <= 2, and the index distance to a saved level is 0 exactly when the
+    level is reproduced."""
+    lut = rr._GRAY_LUT8
+    for i in range(256):
+        assert rr.index_steps_from_levels(np.array([i]), lut[[i]])[0] == 0
+        for j in (i - 1, i + 1):
+            if 0 <= j < 256:
+                assert abs(int(lut[i]) - int(lut[j])) <= 2
+                assert rr.index_steps_from_levels(np.array([i]), lut[[j]])[0] <= 1
+    rng = np.random.default_rng(0)
+    img = rng.random((28, 28))
+    assert (rr._GRAY_LUT8[rr.imsave_gray_index(img)] == rr.imsave_gray_levels(img)).all()
+
+
+@pytest.mark.parametrize("folder", range(5))
+def test_oracle_trajectories_within_one_colour_index_step(folder):
+    steps, cks = _load()
+    x = rr.first_x(42)
+    imgs = [x]
+    for _ in range(5):
+        x = rr.qiddm_pl_forward(x, cks[folder]["weights1"], cks[folder]["linear_up.weight"], cks[folder]["linear_up.bias"])
+        imgs.append(x)
+    ix = rr.indices_from_images(torch.stack(imgs))
+    d = rr.index_steps_from_levels(ix, steps[folder])
+    assert d.max() <= 1 and (d == 0).mean() > 0.999
