@@ -104,6 +104,12 @@ int qiddm_abi_version(void);
 int qiddm_max_qubits(void);
 const char *qiddm_last_error(void);
 
+/* Diagnostics only (tools/stamp_*.py): a device buffer of n_words 64-bit words into which workgroup 0 of the
+ * dense / quantum-convolution kernels writes s_memtime phase stamps (they serialise the kernel: never set it in a
+ * timed run).  The pointer is checked (device memory, the words inside one allocation); NULL / 0 clears it.  There
+ * is no environment-variable form: a stale value inherited from a shell would be a wild GPU write.          */
+int qiddm_set_stamp_buffer(void *device_ptr, int64_t n_words);
+
 /* number of Rot gates = n_rounds*n_blocks*sel_layers*n_qubits (= angles / 3)            */
 int64_t qiddm_num_rot_gates(const qiddm_circuit_t *circ);
 /* gate applications per sample per forward, counted as SURVEY.md section 8a             */

@@ -30,6 +30,7 @@ EXPORTS = (
     "qiddm_abi_version",
     "qiddm_max_qubits",
     "qiddm_last_error",
+    "qiddm_set_stamp_buffer",
     "qiddm_num_rot_gates",
     "qiddm_gate_count",
     "qiddm_gate_table_elems",
@@ -116,6 +117,8 @@ def _declare(lib):
     lib.qiddm_max_qubits.argtypes = []
     lib.qiddm_last_error.restype = ctypes.c_char_p
     lib.qiddm_last_error.argtypes = []
+    lib.qiddm_set_stamp_buffer.restype = ctypes.c_int
+    lib.qiddm_set_stamp_buffer.argtypes = [vp, i64]
     for name in ("qiddm_num_rot_gates", "qiddm_gate_count", "qiddm_gate_table_elems"):
         getattr(lib, name).restype = i64
         getattr(lib, name).argtypes = [P]

@@ -184,16 +184,17 @@ def _scratch(cache: dict, tag, need: int, device, floor: int = 0) -> torch.Tenso
 
 def _workspace(circ: Circuit, precision: str, batch: int, n_replicas: int, device):
     """Per-device scratch for the n > 10 tiled kernel (slabs of concurrently resident workgroups).
-    Returns (ptr, nbytes); (0, 0) when the circuit is register-resident."""
+    Returns (tensor, ptr, nbytes); (None, 0, 0) when the circuit is register-resident.  The caller keeps the TENSOR
+    alive across its launch: during a graph capture it is a fresh allocation that nothing else references."""
     lib = _capi.lib()
     cs = circ.c_struct(precision)
     need = lib.qiddm_workspace_bytes(ctypes.byref(cs), batch, n_replicas)
     if need < 0:
         _capi.check(-1)
     if need == 0:
-        return 0, 0
+        return None, 0, 0
     buf = _scratch(_workspaces, "tiled", need, device)
-    return buf.data_ptr(), need
+    return buf, buf.data_ptr(), need
 
 
 def prepare_gates(circ: Circuit, angles: torch.Tensor, precision: str) -> torch.Tensor:
@@ -214,24 +215,25 @@ def prepare_gates(circ: Circuit, angles: torch.Tensor, precision: str) -> torch.
 
 
 def run_forward(circ: Circuit, inputs, angles: torch.Tensor, precision: str | None = None,
-                table: torch.Tensor | None = None) -> torch.Tensor:
-    """Raw forward (no autograd).  Returns (B, 2^n) probabilities or (B, n) <Z>."""
+                table: torch.Tensor | None = None, batch: int | None = None) -> torch.Tensor:
+    """Raw forward (no autograd).  Returns (B, 2^n) probabilities or (B, n) <Z>.  A circuit without a data encoding
+    (``encoding="none"``: ``inputs`` is None) takes its row count from ``batch``."""
     precision = precision or _default_precision
     dtype = _DT[precision][1]
     _require_device(angles, "the circuit weights")
     device = angles.device
     x, ld, circ2 = _prep_inputs(circ, inputs, dtype, device)
     circ = circ2 or circ
-    if x is None:
-        raise ValueError("run_forward needs inputs to know the batch size; use encoding != 'none'")
-    batch = x.shape[0]
+    if x is None and batch is None:
+        raise ValueError("run_forward needs inputs (or batch=) to know the batch size")
+    batch = x.shape[0] if x is not None else int(batch)
     lib = _capi.lib()
     if table is None:
         table = prepare_gates(circ, angles, precision)
     out = torch.empty(batch, circ.out_cols, dtype=dtype, device=device)
     cs = circ.c_struct(precision)
-    ws_ptr, ws_bytes = _workspace(circ, precision, batch, 0, device)
-    _capi.check(lib.qiddm_forward(ctypes.byref(cs), x.data_ptr(), batch, ld, table.data_ptr(),
+    ws_buf, ws_ptr, ws_bytes = _workspace(circ, precision, batch, 0, device)
+    _capi.check(lib.qiddm_forward(ctypes.byref(cs), 0 if x is None else x.data_ptr(), batch, ld, table.data_ptr(),
                                   out.data_ptr(), circ.out_cols, ws_ptr, ws_bytes, _stream_ptr(device)))
     return out
 
@@ -869,7 +871,7 @@ def run_shift_sweep(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch
     device = angles.device
     x, ld, circ2 = _prep_inputs(circ, inputs, dtype, device)
     circ = circ2 or circ
-    batch = x.shape[0]
+    batch = x.shape[0] if x is not None else grad_out.shape[0]      # encoding "none": one row of grad_out per sample
     lib = _capi.lib()
     cs = circ.c_struct(precision)
     table = prepare_gates(circ, angles, precision)
@@ -886,7 +888,7 @@ def run_shift_sweep(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch
     while first < total:
         cnt = min(chunk, total - first)
         dots = torch.empty(cnt, batch, dtype=dtype, device=device)
-        ws_ptr, ws_bytes = _workspace(circ, precision, batch, cnt, device)
+        ws_buf, ws_ptr, ws_bytes = _workspace(circ, precision, batch, cnt, device)
         _capi.check(lib.qiddm_forward_shifted(ctypes.byref(cs), x.data_ptr(), batch, ld,
                                               table.data_ptr(), g.data_ptr(), g.shape[1], first, cnt,
                                               dots.data_ptr(), ws_ptr, ws_bytes, _stream_ptr(device)))
@@ -916,7 +918,7 @@ def run_adjoint(circ: Circuit, inputs, angles: torch.Tensor, grad_out: torch.Ten
         raise ValueError("run_adjoint differentiates one round")
     x, ld, circ2 = _prep_inputs(circ, inputs, dtype, device)
     circ = circ2 or circ
-    batch = x.shape[0]
+    batch = x.shape[0] if x is not None else grad_out.shape[0]      # encoding "none": one row of grad_out per sample
     lib = _capi.lib()
     cs = circ.c_struct(precision)
     table = prepare_gates(circ, angles, precision)

@@ -15,6 +15,10 @@ constexpr size_t kMaxLds = 160 * 1024;  // per-workgroup LDS on gfx950
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
 int check_circuit(const qiddm_circuit_t* c);
 
+// the buffer registered with qiddm_set_stamp_buffer if it holds at least `need_words` words, else nullptr
+unsigned long long* stamp_buffer(int64_t need_words);
+int set_stamp_buffer(void* device_ptr, int64_t n_words);
+
 // "done once" marker per HIP device: hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device,
 // so a process that drives a second GPU has to repeat it there.  Races are benign (the call is idempotent).
 struct DeviceFlags {

@@ -5,7 +5,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -26,6 +28,43 @@ int fail(int code, const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
   return code;
+}
+
+static std::atomic<unsigned long long*> g_stamp_ptr{nullptr};
+static std::atomic<int64_t> g_stamp_words{0};
+
+unsigned long long* stamp_buffer(int64_t need_words) {
+  unsigned long long* p = g_stamp_ptr.load(std::memory_order_acquire);
+  return (p != nullptr && g_stamp_words.load(std::memory_order_acquire) >= need_words) ? p : nullptr;
+}
+
+int set_stamp_buffer(void* device_ptr, int64_t n_words) {
+  if (device_ptr == nullptr || n_words == 0) {
+    g_stamp_words.store(0, std::memory_order_release);
+    g_stamp_ptr.store(nullptr, std::memory_order_release);
+    return QIDDM_OK;
+  }
+  if (n_words < 8) return fail(QIDDM_ERR_INVALID, "stamp buffer needs at least 8 words (got %lld)", (long long)n_words);
+  if ((reinterpret_cast<uintptr_t>(device_ptr) & 7u) != 0) return fail(QIDDM_ERR_INVALID, "stamp buffer must be 8-byte aligned");
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, device_ptr) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(QIDDM_ERR_INVALID, "stamp buffer %p is not memory the HIP runtime knows", device_ptr);
+  }
+  if (attr.type != hipMemoryTypeDevice)
+    return fail(QIDDM_ERR_INVALID, "stamp buffer %p is not device memory (type %d)", device_ptr, (int)attr.type);
+  hipDeviceptr_t base = nullptr;
+  size_t size = 0;
+  if (hipMemGetAddressRange(&base, &size, device_ptr) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(QIDDM_ERR_INVALID, "cannot query the allocation of stamp buffer %p", device_ptr);
+  }
+  const char* end = static_cast<const char*>(device_ptr) + (size_t)n_words * 8;
+  if (end > static_cast<const char*>(base) + size)
+    return fail(QIDDM_ERR_INVALID, "%lld words at %p run past the end of their allocation", (long long)n_words, device_ptr);
+  g_stamp_ptr.store(static_cast<unsigned long long*>(device_ptr), std::memory_order_release);
+  g_stamp_words.store(n_words, std::memory_order_release);
+  return QIDDM_OK;
 }
 
 int check_circuit(const qiddm_circuit_t* c) {
@@ -585,6 +624,7 @@ int launch_wide_adjoint(const qiddm_circuit_t* c, const void* inputs, const void
 extern "C" {
 
 int qiddm_abi_version(void) { return QIDDM_ABI_VERSION; }
+int qiddm_set_stamp_buffer(void* device_ptr, int64_t n_words) { return qiddm_capi::set_stamp_buffer(device_ptr, n_words); }
 int qiddm_max_qubits(void) { return QIDDM_MAX_QUBITS; }
 
 int64_t qiddm_workspace_bytes(const qiddm_circuit_t* c, int64_t batch, int64_t n_replicas) {
@@ -806,11 +846,27 @@ int64_t qiddm_matrix_adjoint_workspace_bytes(const qiddm_circuit_t* c, int64_t c
   return wide_adjoint_blocks(count) * 2 * ((int64_t)1 << c->n_qubits) * 16;
 }
 
+// The slab format is a function of the descriptor alone (and of the kernel-experiment switches read by make_params /
+// *_eligible): the folded reverse sweeps write per-layer angle-gradient sums, every other producer writes K matrices.
+// qiddm_adjoint_finalize decides by this predicate, so every PRODUCER of slabs has to agree with it.
+static bool finalize_reads_folded_slabs(const qiddm_circuit_t* c) {
+  return (make_params(c).fold && c->n_qubits >= 2 && c->n_qubits <= qiddm::kFoldedAdjointMaxQubits) ||
+         (c->n_qubits > QIDDM_MAX_QUBITS_FUSED && qiddm_capi::wide_cz_adjoint_eligible(c)) ||
+         qiddm_capi::cz10_adjoint_eligible(c);
+}
+
 int qiddm_matrix_adjoint(const qiddm_circuit_t* c, const double* psi0, const double* lambda, int64_t count,
                          const void* gate_table, void* k_partials, void* workspace, int64_t workspace_bytes,
                          void* stream) {
   int rc = check_circuit(c);
   if (rc != QIDDM_OK) return rc;
+  // this entry point always writes K slabs (per-gate sweep); a descriptor that qiddm_adjoint_finalize reads as the
+  // folded layout would come back with wrong gradients and no error -- refuse it here instead
+  if (finalize_reads_folded_slabs(c))
+    return fail(QIDDM_ERR_UNSUPPORTED, "matrix-element sweep writes K slabs, but qiddm_adjoint_finalize reads the "
+                "folded per-layer layout for this circuit (n=%d, %s ring, encoding %d): use a CNOT-ring descriptor "
+                "or qiddm_backward_adjoint[_wide]", c->n_qubits, c->imprimitive == QIDDM_IMP_CZ ? "CZ" : "CNOT",
+                c->encoding);
   if (c->n_rounds != 1) return fail(QIDDM_ERR_UNSUPPORTED, "one round only (n_rounds=%d)", c->n_rounds);
   if (c->dtype != QIDDM_F64) return fail(QIDDM_ERR_UNSUPPORTED, "the matrix-element sweep runs in float64");
   if (c->n_qubits < 2) return fail(QIDDM_ERR_UNSUPPORTED, "the matrix-element sweep needs n_qubits >= 2");
@@ -964,9 +1020,7 @@ int qiddm_adjoint_finalize(const qiddm_circuit_t* c, const double* angles, const
   const int64_t n_rot = (int64_t)c->n_rounds * c->n_blocks * c->sel_layers * c->n_qubits;
   const unsigned blocks = (unsigned)n_rot;  // one wavefront per gate
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if ((make_params(c).fold && c->n_qubits >= 2 && c->n_qubits <= qiddm::kFoldedAdjointMaxQubits) ||
-      (c->n_qubits > QIDDM_MAX_QUBITS_FUSED && qiddm_capi::wide_cz_adjoint_eligible(c)) ||
-      qiddm_capi::cz10_adjoint_eligible(c)) {
+  if (finalize_reads_folded_slabs(c)) {
     // the slabs hold per-layer angle-gradient sums (folded reverse sweep), not K
     const int slots = c->n_qubits <= 8 ? 8 : 16;
     if (c->dtype == QIDDM_F32)
@@ -1031,7 +1085,7 @@ int qiddm_dense_forward(const qiddm_circuit_t* c, const double* x, int64_t batch
   d.out_features = (int32_t)out_features;
   d.post_mode = post_mode;
   d.noise_factor = noise_factor;
-  if (const char* e = std::getenv("QIDDM_STAMP_PTR")) d.stamps = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 0));
+  d.stamps = qiddm_capi::stamp_buffer(8);
   hipStream_t st = static_cast<hipStream_t>(stream);
   return c->dtype == QIDDM_F32
              ? dispatch_dense<float>(c->n_qubits, x, w_down, b_down, angles, w_up, b_up, y, d, p, st)
@@ -1114,7 +1168,7 @@ int qiddm_dense_sample(const qiddm_circuit_t* c, const double* x, int64_t batch,
   d.post_mode = post_mode;
   d.n_steps = n_steps;
   d.noise_factor = noise_factor;
-  if (const char* e = std::getenv("QIDDM_STAMP_PTR")) d.stamps = reinterpret_cast<unsigned long long*>(std::strtoull(e, nullptr, 0));
+  d.stamps = qiddm_capi::stamp_buffer(8);
   hipStream_t st = static_cast<hipStream_t>(stream);
   return c->dtype == QIDDM_F32
              ? dispatch_quad<float>(c->n_qubits, x, w_down, b_down, angles, w_up, b_up, y, tables, d, p, st)

@@ -208,7 +208,7 @@ int qiddm_qconv_unitary_forward(int32_t n_qubits, const double* u, const double*
   gc.M = g.m;
   gc.pad_norm2 = 0.25 * (double)(d - f);
   gc.post_scale = 0.5 * (double)d;
-  if (const char* ev = std::getenv("QIDDM_STAMP_PTR")) gc.stamps = reinterpret_cast<unsigned long long*>(std::strtoull(ev, nullptr, 0));
+  gc.stamps = qiddm_capi::stamp_buffer(8);
   const int64_t mblocks = (g.m + qiddm::kGemmM - 1) / qiddm::kGemmM;
   if (mblocks > 0x7fffffff) return fail(QIDDM_ERR_UNSUPPORTED, "too many output pixels for one launch");
 #define QIDDM_GEMM_LAUNCH(GRID_Y, ...)                                                                             \
@@ -390,7 +390,7 @@ int train_backward(int32_t n_qubits, const void* x, bool x32, int64_t batch, int
   tc.pad_norm2 = 0.25f * (float)(d - f);
   tc.post_scale = 0.5f * (float)d;
   tc.groups = train_groups(f);
-  if (const char* ev = std::getenv("QIDDM_STAMP_PTR")) tc.stamps = reinterpret_cast<unsigned long long*>(std::strtoull(ev, nullptr, 0));
+  tc.stamps = qiddm_capi::stamp_buffer(8);
   const unsigned grid = (unsigned)train_grid(batch * ho * wo, f);
   hipStream_t st = static_cast<hipStream_t>(stream);
   size_t smem = 0;

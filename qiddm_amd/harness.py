@@ -147,6 +147,20 @@ def train(diff, loader, args, start_epoch=0, loss_values=None):
                 # every rank sees the global batch (same seeded loader), takes its contiguous shard -- possibly
                 # uneven or empty -- and weights its gradient / loss by local_n / global_n
                 lo, hi = parallel.shard_bounds(x.shape[0], dist.get_rank(), world)
+                if use_graph and x.shape[0] >= world:
+                    # --graph under data parallelism: the recorded step (gradient all-reduce inside the graph for RCCL)
+                    # for the first global batch shape; the decision depends on the GLOBAL shape only, so every rank
+                    # takes the same branch.  Other shapes (an epoch's last, smaller batch) run the eager DP step.
+                    key = ("dp", tuple(x.shape))
+                    if not recorded:
+                        cpu_rng = torch.get_rng_state()
+                        recorded[key] = GraphedTrainStep(diff, opt, x[lo:hi], T=args.tau, noise="reference",
+                                                         shard=(x.shape[0], lo, hi))
+                        torch.set_rng_state(cpu_rng)
+                    step = recorded.get(key)
+                    if step is not None:
+                        epoch_loss += step(x[lo:hi])[0].mean() * ((hi - lo) / x.shape[0])
+                        continue
                 out = dp_step(x, T=args.tau, verbose=True)
                 if out is not None:
                     epoch_loss += out[0].mean() * ((hi - lo) / x.shape[0])

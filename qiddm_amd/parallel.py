@@ -185,6 +185,21 @@ class ShardedNoise:
         return self.base(data, tau, decay_mod, noise=self.noise_field(data))
 
 
+class GlobalSliceNoise:
+    """Fallback for noise functions WITHOUT the ``noise_field`` marker (anything but ``add_normal_noise_multiple``):
+    every rank runs the function on the GLOBAL batch -- so each draws what the single process would, and all generators
+    stay in lock-step whatever the shard sizes -- and keeps the rows of its own samples (the output is batch-major,
+    ``tau`` rows per sample: reference src/noise.py:121-126)."""
+
+    def __init__(self, base_noise_f, x_global: torch.Tensor, lo: int, hi: int):
+        self.base, self.x_global, self.lo, self.hi = base_noise_f, x_global, int(lo), int(hi)
+
+    def __call__(self, data, tau, decay_mod=1.0):
+        n = self.x_global.shape[0]
+        whole = self.base(self.x_global.reshape(n, -1), tau, decay_mod)
+        return whole.reshape(n, tau, -1)[self.lo:self.hi].reshape((self.hi - self.lo) * tau, -1)
+
+
 class DataParallelStep:
     """One data-parallel step of the reference's hot loop 1 (src/mnist_exm.py:179-182):
     ``zero_grad -> diff(x_local, T) [forward + backward] -> gradient all-reduce -> optimizer.step()`` on this rank's
@@ -205,14 +220,18 @@ class DataParallelStep:
         else:
             self.bucket.zero()
         out = None
-        sharded = world > 1 and getattr(self._noise_f, "noise_field", None) is not None
-        if sharded:
-            self.diff.add_noise = ShardedNoise(self._noise_f, n, lo, hi)
+        has_field = getattr(self._noise_f, "noise_field", None) is not None
+        if world > 1:
+            self.diff.add_noise = ShardedNoise(self._noise_f, n, lo, hi) if has_field else \
+                GlobalSliceNoise(self._noise_f, x_global, lo, hi)
         try:
             if hi > lo:
                 out = self.diff(x=x_local, T=T, verbose=verbose)
-            elif sharded:
-                self.diff.add_noise.noise_field(x_global[:1])       # keep the generator in lock-step
+            elif world > 1:                                          # keep the generator in lock-step
+                if has_field:
+                    self.diff.add_noise.noise_field(x_global[:1])
+                else:
+                    self._noise_f(x_global.reshape(n, -1), T + 1, 3.0)   # what Diffusion._noisy_clean_pairs would draw
         finally:
             self.diff.add_noise = self._noise_f
         if self.bucket is None:

@@ -144,6 +144,7 @@ class GraphedTrainStep:
             fused = dist.get_backend() == "nccl" and os.environ.get("QIDDM_DP_GRAPH", "fused") != "split"
             if fused:
                 # RCCL collectives are capturable: zero -> forward+backward -> all-reduce -> Adam is ONE graph
+                failure = None
                 try:
                     with torch.cuda.graph(self.g_fwd_bwd):
                         self.bucket.zero()
@@ -151,9 +152,21 @@ class GraphedTrainStep:
                         self.bucket.all_reduce(self.dp_weight, force=self.force_dp)
                         self.opt.step()
                 except Exception as e:     # pragma: no cover - depends on the RCCL build
+                    failure = e
+                # the ranks must replay the SAME form (a rank with the collective inside its graph and a rank that
+                # calls it eagerly would not pair up): agree on the minimum of the success flags
+                torch.cuda.synchronize()
+                ok = torch.tensor([0 if failure is not None else 1], dtype=torch.int32, device=self.x.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:    # pragma: no cover - depends on the RCCL build
                     import warnings
-                    warnings.warn(f"capturing the gradient all-reduce failed ({e!r}); recording two graphs around it")
+                    warnings.warn(f"capturing the gradient all-reduce failed on some rank ({failure!r} here); every "
+                                  f"rank records two graphs around an eager all-reduce instead")
                     fused = False
+                    # a capture that threw may have left its stream's capture state invalid: drop the graph object,
+                    # drain the device, and record again from a clean state
+                    self.g_fwd_bwd = None
+                    torch.cuda.synchronize()
                     self.g_fwd_bwd = torch.cuda.CUDAGraph()
             if not fused:
                 with torch.cuda.graph(self.g_fwd_bwd):

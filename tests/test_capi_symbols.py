@@ -68,3 +68,19 @@ def test_invalid_descriptors_are_rejected_with_a_reason(hip_lib):
     cs = Circuit(3).c_struct("f32")
     cs.sel_layers = 0
     assert hip_lib.qiddm_num_rot_gates(ctypes.byref(cs)) == -1
+
+
+def test_matrix_adjoint_refuses_descriptors_finalize_reads_as_folded(hip_lib):
+    """`qiddm_matrix_adjoint` always writes K slabs; for a CZ descriptor `qiddm_adjoint_finalize` would read the folded
+    layout and return wrong gradients silently (round-2 advice) -- the producer refuses such a descriptor."""
+    import ctypes
+    from qiddm_amd.circuit import Circuit
+    for n in (8, 10, 12, 16):
+        cs = Circuit(n_qubits=n, encoding="none", imprimitive="CZ", measure="probs", n_rounds=1, n_blocks=1,
+                     sel_layers=3).c_struct("f64")
+        rc = hip_lib.qiddm_matrix_adjoint(ctypes.byref(cs), None, None, 2, None, None, None, 0, None)
+        assert rc == -2 and b"folded" in hip_lib.qiddm_last_error(), (n, rc, hip_lib.qiddm_last_error())
+    cs = Circuit(n_qubits=12, encoding="none", imprimitive="CNOT", measure="probs", n_rounds=1, n_blocks=1,
+                 sel_layers=3).c_struct("f64")
+    rc = hip_lib.qiddm_matrix_adjoint(ctypes.byref(cs), None, None, 2, None, None, None, 0, None)
+    assert rc == -1 and b"NULL" in hip_lib.qiddm_last_error()          # accepted as a descriptor; the NULLs are next

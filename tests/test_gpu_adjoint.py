@@ -354,3 +354,33 @@ def test_cz10_adjoint_vs_oracle_autograd(L, S, meas, B, precision, tol):
     assert (ga.cpu() - wo.grad).abs().max().item() < tol * sw, (ga.cpu() - wo.grad).abs().max().item() / sw
     sx = max(xo.grad.abs().max().item(), 1e-3)
     assert (gi.cpu() - xo.grad).abs().max().item() < tol * sx, (gi.cpu() - xo.grad).abs().max().item() / sx
+
+
+# ---- circuits WITHOUT a data encoding (inputs = NULL at the C ABI) on the pass-structured CZ kernels -----------------
+@pytest.mark.parametrize("n,L,S,meas,B", [(10, 3, 2, "probs", 5), (10, 1, 3, "expz", 3), (12, 2, 2, "expz", 4),
+                                          (12, 3, 1, "probs", 3), (16, 2, 2, "expz", 3), (16, 1, 2, "probs", 2)])
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-9), ("f32", 2e-4)])
+def test_cz_kernels_without_encoding_forward_and_adjoint(n, L, S, meas, B, precision, tol):
+    """`wide_cz_kernel` / `wide_cz_adjoint_kernel` (n = 12, 16) and the 10-qubit `circuit_kernel` / `cz10_adjoint_kernel`
+    accept QIDDM_ENC_NONE (inputs = NULL, no block-start re-upload; round-2 advice: every earlier case used "rz").
+    Forward and weight gradients against the oracle and autograd through it; every sample is the same circuit, the
+    gradient still sums their different upstream rows."""
+    from oracle import circuits as oc
+    from qiddm_amd.circuit import Circuit, run_adjoint, run_forward
+    g_ = torch.Generator().manual_seed(77 * n + 10 * L + S)
+    circ = Circuit(n_qubits=n, encoding="none", imprimitive="CZ", measure=meas, n_rounds=1, n_blocks=L, sel_layers=S)
+    w = torch.randn(circ.angles_shape, generator=g_, dtype=torch.float64) * 0.6
+    cols = (1 << n) if meas == "probs" else n
+    g = torch.randn(B, cols, generator=g_, dtype=torch.float64)
+    wo = w.clone().requires_grad_(True)
+    spec = oc.Spec(n=n, encoding="none", imprimitive="CZ", measure=meas)
+    ref = oc.run_circuit(spec, torch.zeros(B, n, dtype=torch.float64), wo)
+    (ref * g).sum().backward()
+    out = run_forward(circ, None, w.cuda(), precision, batch=B)
+    assert out.shape == (B, cols)
+    ftol = 1e-11 if precision == "f64" else 2e-5
+    assert (out.cpu().double() - ref.detach()).abs().max().item() < ftol
+    ga, gi = run_adjoint(circ, None, w.cuda(), g.cuda(), precision)
+    assert gi is None
+    sw = max(wo.grad.abs().max().item(), 1e-3)
+    assert (ga.cpu() - wo.grad).abs().max().item() < tol * sw, (ga.cpu() - wo.grad).abs().max().item() / sw

@@ -178,3 +178,61 @@ def test_grad_bucket_views_single_process():
     torch.optim.SGD(net.parameters(), lr=0.1).zero_grad(set_to_none=True)
     with pytest.raises(RuntimeError):
         b.check_views()
+
+
+# ---- a noise function WITHOUT the noise_field marker: drawn for the global batch on every rank, rows sliced ----------
+def _plain_random_noise(data, tau, decay_mod=1.0):
+    """Not add_normal_noise_multiple: no `noise_field` / `schedule` attributes, draws from the default CPU generator."""
+    field = torch.rand(data.shape[0], data.shape[1], dtype=data.dtype)
+    w = (torch.linspace(0, 1, tau, dtype=data.dtype) ** decay_mod).reshape(1, tau, 1)
+    return (data.unsqueeze(1) * (1 - w) + field.unsqueeze(1) * w).reshape(data.shape[0] * tau, -1)
+
+
+def _dp_fallback_worker(rank, world, port, ret, batch_sizes):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from qiddm_amd import models, parallel
+        torch.manual_seed(100)
+        net = TinyNet()
+        diff = models.Diffusion(net, _plain_random_noise, "data", (8, 8), torch.nn.MSELoss())
+        diff.train()
+        opt = torch.optim.Adam(diff.parameters(), lr=0.05)
+        step = parallel.DataParallelStep(diff, opt)
+        torch.manual_seed(7)
+        for n in batch_sizes:
+            step(torch.rand(n, 64, dtype=torch.double), T=4)
+        ret[rank] = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        ret[f"rng{rank}"] = torch.get_rng_state()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_dp2_unmarked_noise_function_is_drawn_globally_and_sliced():
+    """Round-2 advice: without `noise_field` every rank drew a LOCAL-size field from the same-seeded generator (identical
+    noise on every rank, generators drifting apart on uneven shards).  Now: the global draw, sliced -> DP-2 equals the
+    single-process run and the generators end equal, uneven (3 + 2) and empty (1 + 0) shards included."""
+    world, batch_sizes = 2, (5, 1, 4)
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_dp_fallback_worker, args=(world, port, ret, batch_sizes), nprocs=world, join=True)
+    assert torch.equal(ret["rng0"], ret["rng1"])
+    from qiddm_amd import models
+    torch.manual_seed(100)
+    net = TinyNet()
+    diff = models.Diffusion(net, _plain_random_noise, "data", (8, 8), torch.nn.MSELoss())
+    diff.train()
+    opt = torch.optim.Adam(diff.parameters(), lr=0.05)
+    torch.manual_seed(7)
+    for n in batch_sizes:
+        x_global = torch.rand(n, 64, dtype=torch.double)
+        opt.zero_grad()
+        diff(x=x_global, T=4)
+        opt.step()
+    for k, v in net.state_dict().items():
+        tol = 1e-12 if v.dtype == torch.float64 else 1e-6
+        assert torch.allclose(ret[0][k], v, atol=tol, rtol=1e-10), (k, (ret[0][k] - v).abs().max())
+        assert torch.equal(ret[0][k], ret[1][k]), k
+    assert torch.equal(ret["rng0"], torch.get_rng_state())

@@ -5,7 +5,8 @@ import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 buf = torch.zeros(8, dtype=torch.int64, device="cuda")
-os.environ["QIDDM_STAMP_PTR"] = str(buf.data_ptr())
+from qiddm_amd import _capi  # noqa: E402
+_capi.check(_capi.lib().qiddm_set_stamp_buffer(buf.data_ptr(), buf.numel()))
 from qiddm_amd.circuit import Circuit, dense_forward  # noqa: E402
 for (n, N, L, S, P, B) in [(8, 1, 1, 14, 784, 256), (8, 1, 1, 1, 784, 256), (8, 1, 1, 14, 784, 4096)]:
     circ = Circuit(n_qubits=n, encoding="rz", imprimitive="CZ", measure="expz", n_rounds=N, n_blocks=L, sel_layers=S)

@@ -5,7 +5,8 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 buf = torch.zeros(8, dtype=torch.int64, device="cuda")
-os.environ["QIDDM_STAMP_PTR"] = str(buf.data_ptr())
+from qiddm_amd import _capi  # noqa: E402
+_capi.check(_capi.lib().qiddm_set_stamp_buffer(buf.data_ptr(), buf.numel()))
 from qiddm_amd import nn  # noqa: E402
 
 torch.manual_seed(0)
