@@ -501,20 +501,26 @@ def secondary_c3_circuits(dev, out):
         out["error_C3_QDenseUndirected_old_noise"] = repr(e)
 
 
-def _qconv_layer_shapes(unet, x):
-    """(patch features, output channels, output pixels) of every quantum convolution in one forward of `unet`."""
+def _qconv_layer_shapes(unet, batch):
+    """(patch features, output channels, output pixels) of every quantum convolution in one forward of `unet` on
+    `batch` 28 x 28 images.  Taken from forward hooks on a training-mode COPY run on two images (the eval-mode net
+    fuses whole layer pairs into one launch and never enters QConv2d.forward) and scaled to the batch."""
+    import copy
     from qiddm_amd import nn
+    probe = copy.deepcopy(unet).train()
     shapes, hooks = [], []
-    for m in unet.modules():
+    for m in probe.modules():
         if isinstance(m, nn.QConv2d):
             hooks.append(m.register_forward_hook(
                 lambda mod, inp, outp: shapes.append((mod.in_channels * mod.kernel_size[0] * mod.kernel_size[1],
                                                       mod.out_channels, outp.numel() // mod.out_channels))))
+    dev = next(probe.parameters()).device
     with torch.no_grad():
-        unet(x)
+        probe(torch.rand(2, 1, IMG, IMG, dtype=torch.double, device=dev))
     for h in hooks:
         h.remove()
-    return shapes
+    assert shapes, "no QConv2d forward was seen"
+    return [(k, c, px * batch // 2) for k, c, px in shapes]
 
 
 def secondary_unet(dev, out, batch):
@@ -531,7 +537,7 @@ def secondary_unet(dev, out, batch):
             torch.manual_seed(42)
             unet = nn.UNetUndirectedS(3, 8, 3).to(dev, dtype=torch.double).eval()
             xb = (torch.rand(b, 1, IMG, IMG, dtype=torch.double) * 0.75 + 0.5).to(dev)
-            flop = sum(2.0 * k * 2 * c * px for k, c, px in _qconv_layer_shapes(unet, xb))
+            flop = sum(2.0 * k * 2 * c * px for k, c, px in _qconv_layer_shapes(unet, b))
             with torch.no_grad():
                 t = _time_fn(lambda: unet(xb), 5, warm=1)
                 out[f"denoise_images_per_s_{tag}"] = b / t
@@ -566,9 +572,7 @@ def secondary_unet(dev, out, batch):
             gstep = GraphedTrainStep(diff, opt, xt, T=10, noise="device")
             tg = _time_fn(lambda: gstep(xt), 5 if b >= 1024 else 20, warm=2)
             out[f"train_images_per_s_{tag}_graphed"] = b * 10 / tg
-            unet_t.eval()
-            flop = 4 * sum(2.0 * k * 2 * c * px for k, c, px in
-                           _qconv_layer_shapes(unet_t, torch.rand(b * 10, 1, IMG, IMG, dtype=torch.double, device=dev)))
+            flop = 4 * sum(2.0 * k * 2 * c * px for k, c, px in _qconv_layer_shapes(unet_t, b * 10))
             tf = flop / tg / 1e12
             out[f"roofline_{tag}"] = {"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TF, "unit": "TFLOP/s",
                                       "frac": tf / VALU_PEAK_TF,

@@ -48,6 +48,10 @@ EXPORTS = (
     "qiddm_dense_sample",
     "qiddm_dense_sample_tables_bytes",
     "qiddm_dense_sample_prepare",
+    "qiddm_dense_sample_lean_tables_bytes",
+    "qiddm_dense_sample_lean_prepare",
+    "qiddm_dense_sample_lean_check",
+    "qiddm_dense_sample_lean",
     "qiddm_qconv_forward",
     "qiddm_qconv_backward",
     "qiddm_train_workspace_bytes",
@@ -142,6 +146,14 @@ def _declare(lib):
     lib.qiddm_dense_sample_tables_bytes.argtypes = [P]
     lib.qiddm_dense_sample_prepare.restype = ctypes.c_int
     lib.qiddm_dense_sample_prepare.argtypes = [P, vp, vp, vp]
+    lib.qiddm_dense_sample_lean_tables_bytes.restype = i64
+    lib.qiddm_dense_sample_lean_tables_bytes.argtypes = [P]
+    lib.qiddm_dense_sample_lean_prepare.restype = ctypes.c_int
+    lib.qiddm_dense_sample_lean_prepare.argtypes = [P, vp, vp, vp, vp, vp, i64, vp, vp]
+    lib.qiddm_dense_sample_lean_check.restype = ctypes.c_int
+    lib.qiddm_dense_sample_lean_check.argtypes = [P, vp, vp]
+    lib.qiddm_dense_sample_lean.restype = ctypes.c_int
+    lib.qiddm_dense_sample_lean.argtypes = [P, vp, i64, i64, i64, vp, vp, vp, vp, ctypes.c_int32, vp, i64, i64, vp, vp]
     lib.qiddm_adjoint_partials.restype = i64
     lib.qiddm_adjoint_partials.argtypes = [P, i64]
     lib.qiddm_backward_adjoint.restype = ctypes.c_int

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libqiddm_hip.so")
 SOURCES = ["qiddm_capi.hip", "qiddm_train.hip", "qiddm_qconv.hip", "qiddm_mixed.hip", "qiddm_norm.hip",
-           "qiddm_wide.hip", "qiddm_cz10.hip"]
+           "qiddm_wide.hip", "qiddm_cz10.hip", "qiddm_quad8.hip"]
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
 
@@ -33,12 +33,46 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (expected on PATH or at /opt/rocm/bin/hipcc)")
 
 
+_INC = __import__("re").compile(r'^\s*#\s*include\s+"([^"]+)"', __import__("re").M)
+
+
+def _deps(path: str, seen=None) -> set:
+    """`path` and every file it includes with quotes, transitively (the translation units share headers unevenly:
+    a change to one kernel header should not rebuild all of them)."""
+    seen = set() if seen is None else seen
+    path = os.path.normpath(path)
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path) as f:
+        text = f.read()
+    for inc in _INC.findall(text):
+        _deps(os.path.join(os.path.dirname(path), inc), seen)
+    return seen
+
+
+def _obj_of(src: str) -> str:
+    return os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+
+
+def _stale_sources() -> list:
+    out = []
+    for src in SOURCES:
+        obj = _obj_of(src)
+        if not os.path.exists(obj):
+            out.append(src)
+            continue
+        t = os.path.getmtime(obj)
+        if any(os.path.getmtime(d) > t for d in _deps(os.path.join(CSRC, src))):
+            out.append(src)
+    return out
+
+
 def _stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + _headers()
-    return any(os.path.getmtime(d) > t for d in deps)
+    return bool(_stale_sources()) or any(os.path.getmtime(_obj_of(s)) > t for s in SOURCES)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -46,19 +80,18 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = _hipcc()
-    # one object per translation unit, compiled side by side, then one link
+    # one object per translation unit whose sources changed, compiled side by side, then one link
     procs = []
-    for src in SOURCES:
-        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+    for src in (SOURCES if force else _stale_sources()):
+        obj = _obj_of(src)
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print("[qiddm_amd.build]", " ".join(cmd), flush=True)
         procs.append((cmd, obj, subprocess.Popen(cmd, cwd=CSRC)))
-    objs = []
     for cmd, obj, proc in procs:
         if proc.wait() != 0:
             raise subprocess.CalledProcessError(proc.returncode, cmd)
-        objs.append(obj)
+    objs = [_obj_of(src) for src in SOURCES]
     link = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs
     if verbose:
         print("[qiddm_amd.build]", " ".join(link), flush=True)

@@ -315,6 +315,58 @@ def dense_sample(circ: Circuit, x: torch.Tensor, w_down, b_down, angles, w_up, b
     return y
 
 
+# QIDDM_NO_LEAN_SAMPLER=1: keep the general four-wavefront sampler for every net (kernel experiments: A/B on one box)
+_LEAN_SAMPLER = os.environ.get("QIDDM_NO_LEAN_SAMPLER", "0") != "1"
+
+
+def dense_sample_lean_tables(circ: Circuit, angles, w_down, b_down, w_up, b_up, precision: str | None = None):
+    """Tables of the lean sampling loop of the 8-qubit dense nets (``qiddm_dense_sample_lean_prepare``: tangent-form
+    layers + the 8 x 8 map ``W_down W_up`` of the next step's angles), or None when the circuit is outside that
+    kernel's family, the weights are outside the tangent form's range (``qiddm_dense_sample_lean_check``), or a HIP
+    graph is being captured (the check reads one number back: build the tables once before recording)."""
+    if not _LEAN_SAMPLER or circ.n_qubits != 8 or circ.encoding != "rz" or circ.imprimitive != "CZ" \
+            or circ.measure != "expz" or torch.cuda.is_current_stream_capturing():
+        return None
+    precision = precision or _default_precision
+    device = angles.device
+    ang = _as_f64(angles.detach(), device)
+    wd, bd, wu, bu = (_as_f64(t, device) for t in (w_down, b_down, w_up, b_up))
+    if tuple(ang.shape) != circ.angles_shape or wd.shape[0] != 8 or wu.shape != (wd.shape[1], 8) or wd.shape[1] > 2048:
+        return None
+    lib = _capi.lib()
+    cs = circ.c_struct(precision)
+    need = lib.qiddm_dense_sample_lean_tables_bytes(ctypes.byref(cs))
+    if need < 0:
+        return None                                  # e.g. deep float64 circuits whose tables do not fit in LDS
+    tables = torch.empty(need, dtype=torch.uint8, device=device)
+    st = _stream_ptr(device)
+    _capi.check(lib.qiddm_dense_sample_lean_prepare(ctypes.byref(cs), ang.data_ptr(), wd.data_ptr(),
+                                                    0 if bd is None else bd.data_ptr(), wu.data_ptr(),
+                                                    0 if bu is None else bu.data_ptr(), wd.shape[1], tables.data_ptr(), st))
+    ok = lib.qiddm_dense_sample_lean_check(ctypes.byref(cs), tables.data_ptr(), st)
+    if ok < 0:
+        _capi.check(ok)
+    return tables if ok == 1 else None
+
+
+def dense_sample_lean(circ: Circuit, x: torch.Tensor, w_down, b_down, w_up, b_up, n_steps: int, tables: torch.Tensor,
+                      precision: str | None = None):
+    """``n_steps`` bodies of the sampling loop for goal "data" in ONE launch of the lean kernel
+    (``qiddm_dense_sample_lean``).  Returns (n_steps, batch, features) float64."""
+    precision = precision or _default_precision
+    _require_device(x, "the input batch")
+    device = tables.device
+    xx = _as_f64(x, device)
+    wd, bd, wu, bu = (_as_f64(t, device) for t in (w_down, b_down, w_up, b_up))
+    y = torch.empty(n_steps, xx.shape[0], wu.shape[0], dtype=torch.float64, device=device)
+    cs = circ.c_struct(precision)
+    _capi.check(_capi.lib().qiddm_dense_sample_lean(
+        ctypes.byref(cs), xx.data_ptr(), xx.shape[0], xx.stride(0), xx.shape[1], wd.data_ptr(),
+        0 if bd is None else bd.data_ptr(), wu.data_ptr(), 0 if bu is None else bu.data_ptr(), int(n_steps),
+        y.data_ptr(), y.stride(1), y.stride(0), tables.data_ptr(), _stream_ptr(device)))
+    return y
+
+
 def circuit_unitary(angles: torch.Tensor, n_qubits: int, imprimitive: str = "CNOT",
                     precision: str = "f64") -> torch.Tensor:
     """``qml.matrix`` of ``StronglyEntanglingLayers(angles (S, n, 3), imprimitive)`` with

@@ -1,0 +1,421 @@
+// qsim_quad8.h -- the sampling loop of the 8-qubit dense nets with the layer's dependent chain cut to the bone.
+//
+// Same decomposition as qsim_quad.h (four wavefronts per sample, amplitude k = (wave << 6) | lane, one LDS exchange per
+// layer for the two wave-bit gates), but built around what the microbenchmark of tools/ubench/ubench_quad.hip says a
+// LONE wavefront on a SIMD pays: ~11 cycles per DEPENDENT vector instruction whatever it is, ~155 cycles for the LDS
+// round trip + barrier.  A layer is a dependent chain (every gate acts on the same amplitudes), so its time is
+// (chain depth) x 11 + 155 and the only lever is depth:
+//
+//   * RY in tangent form.  RY = c [[1, -t], [t, 1]], t = tan(theta / 2): own' = own +- t * partner is ONE instruction
+//     whose partner operand is fetched by DPP inside it (`v_fmac_f32_dpp`, accumulator = own value, in place) --
+//     depth 1 per lane-bit gate instead of 3 (dpp mov, wait state, packed fma behind a packed multiply).  The factors c
+//     of a layer commute with everything and are folded into that layer's phase table, so they cost nothing.
+//   * the row-crossing bits 4 / 5 keep the permlane swap of (re, im) (qsim_quad.h), with the 2 x 2 in tangent form:
+//     swap, one fma per member, swap -- depth 3 instead of 4.
+//   * the wave-bit 4 x 4 in tangent form: own + k1 p1 + k2 p2 + k3 p3 with per-wave k = +-t6, +-t7, their product;
+//     nothing to multiply before the barrier.
+//   * per-layer data (this thread's phase, eight tangents) is read one layer ahead while the exchange is in flight,
+//     into one of two register sets that alternate (no copies).
+//   * linear_down is NOT evaluated per step: with goal = "data" the loop is x <- net(x) with no clamp (reference
+//     src/models.py:127-129), so the next step's angles are (W_down W_up) z + (W_down b_up + b_down) with z = <Z> of
+//     this step -- an 8 x 8 product built once per weights (quad8_tables_kernel).  Where the angles cannot reach the
+//     state at all (one block per round: RZ on |0..0> is a global phase, finding F2) they are not computed.
+//
+// The tangent form needs cos(theta / 2) away from zero: the table builder records max |t|; the host routes weights with
+// max |t| > kQuad8MaxTan to dense_quad_kernel (qiddm_dense_sample_lean_check).  Shipped checkpoints have |theta / 2| < 0.9.
+#pragma once
+#include "qsim_quad.h"
+
+namespace qiddm {
+
+constexpr double kQuad8MaxTan = 16.0;
+constexpr int kQuad8HeaderDoubles = 80;   // [0] max |t|, [1..64] M = W_down W_up (row-major [j][i]), [65..72] v, pad
+
+// layout of the lean tables behind the header, in elements of T (built once per weights, copied to LDS per launch)
+template <typename T>
+struct Quad8Tables {
+  // per layer: ph[256] complex (thread order), un[8] = t of index bits 0..7
+  __host__ __device__ static constexpr size_t ph_elems(int layers) { return (size_t)layers * 256 * 2; }
+  __host__ __device__ static constexpr size_t un_elems(int layers) { return (size_t)layers * 8; }
+  __host__ __device__ static constexpr size_t a0_elems(int rounds) { return (size_t)rounds * 256; }
+  __host__ __device__ static size_t elems(int layers, int rounds) {
+    return ph_elems(layers) + un_elems(layers) + a0_elems(rounds);
+  }
+  __host__ __device__ static size_t bytes(int layers, int rounds) {
+    return (size_t)kQuad8HeaderDoubles * sizeof(double) + elems(layers, rounds) * sizeof(T);
+  }
+  // LDS of dense_quad8_kernel: the tables, the double-buffered exchange slab, partial sums and per-wave angle copies
+  __host__ __device__ static size_t lds_bytes(int layers, int rounds) {
+    return (elems(layers, rounds) * sizeof(T) + 15) / 16 * 16 + (size_t)2 * 4 * kWave * 2 * sizeof(T) +
+           (size_t)(3 * 4 * 16 + 3 * 4 * 16) * sizeof(double);
+  }
+};
+
+// ---- table builder: one 256-thread workgroup --------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void quad8_tables_kernel(const double* __restrict__ angles,
+                                                           const double* __restrict__ wd, const double* __restrict__ bd,
+                                                           const double* __restrict__ wu, const double* __restrict__ bu,
+                                                           int features, unsigned char* __restrict__ tables,
+                                                           const KScalars p) {
+  constexpr int N = 8;
+  using C = V2<T>;
+  __shared__ double s_alpha[1024];   // phi^l_w + omega^{l-1}_w per (layer, wire): layers <= 128
+  __shared__ double s_c[1024], s_s[1024];
+  __shared__ double s_max[256];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lpr = p.n_blocks * p.sel_layers, layers = p.n_rounds * lpr, n_rot = layers * N;
+  double* head = reinterpret_cast<double*>(tables);
+  T* body = reinterpret_cast<T*>(tables + kQuad8HeaderDoubles * sizeof(double));
+  C* ph = reinterpret_cast<C*>(body);
+  T* un = body + Quad8Tables<T>::ph_elems(layers);
+  T* a0 = un + Quad8Tables<T>::un_elems(layers);
+  double tmax = 0.0;
+  for (int g = tid; g < n_rot; g += 256) {
+    double c, sn;
+    sincos(0.5 * angles[g * 3 + 1], &sn, &c);
+    s_c[g] = c;
+    s_s[g] = sn;
+    const int li = (g / N) % lpr;
+    s_alpha[g] = angles[g * 3 + 0] + (li > 0 ? angles[(g - N) * 3 + 2] : 0.0);
+    if (li > 0) {                                   // a round's first layer is generated from (c, s), never divided
+      const double t = c != 0.0 ? fabs(sn / c) : 1e300;
+      tmax = fmax(tmax, t);
+      const int w = g % N;
+      un[(g / N) * 8 + (N - 1 - w)] = (T)(c != 0.0 ? sn / c : 0.0);     // t of index bit q = N-1-w
+    } else {
+      un[(g / N) * 8 + (N - 1 - (g % N))] = (T)0;
+    }
+  }
+  s_max[tid] = tmax;
+  __syncthreads();
+  if (tid == 0) {
+    double m = 0.0;
+    for (int i = 0; i < 256; ++i) m = fmax(m, s_max[i]);
+    head[0] = m;
+  }
+  const uint32_t k = ((uint32_t)wv << 6) | (uint32_t)logical_lane(lane);   // this thread's amplitude index
+  for (int l = 0; l < layers; ++l) {
+    const int li = l % lpr;
+    if (li == 0) {
+      // the round's first layer acts on |0..0>: a real product state (its diagonal is a global phase)
+      double f = 1.0;
+#pragma unroll
+      for (int q = 0; q < N; ++q) f *= ((k >> q) & 1u) ? s_s[l * N + (N - 1 - q)] : s_c[l * N + (N - 1 - q)];
+      a0[(l / lpr) * 256 + tid] = (T)f;
+      ph[l * 256 + tid] = C{(T)1, (T)0};
+      continue;
+    }
+    double ang = 0.0, scale = 1.0;
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+      const double al = s_alpha[l * N + (N - 1 - q)];
+      ang += ((k >> q) & 1u) ? 0.5 * al : -0.5 * al;
+      scale *= s_c[l * N + q];                       // every factor cos(theta_w / 2) of THIS layer's RYs
+    }
+    double c, sn;
+    sincos(ang, &sn, &c);
+    if (cz_ring_parity<N>(k, ((li - 1) % p.sel_layers) % (N - 1) + 1)) scale = -scale;   // CZ ring of the layer before
+    ph[l * 256 + tid] = C{(T)(c * scale), (T)(sn * scale)};
+  }
+  // M = W_down W_up and v = W_down b_up + b_down (float64): the angles of the NEXT step from this step's <Z>
+  if (wd != nullptr && wu != nullptr && tid < 72) {
+    const int j = tid < 64 ? tid / 8 : tid - 64, i = tid % 8;
+    double acc = 0.0;
+    if (tid < 64) {
+      for (int px = 0; px < features; ++px) acc = fma(wd[(size_t)j * features + px], wu[(size_t)px * N + i], acc);
+      head[1 + tid] = acc;
+    } else {
+      for (int px = 0; px < features; ++px) acc = fma(wd[(size_t)j * features + px], bu ? bu[px] : 0.0, acc);
+      head[65 + j] = acc + (bd ? bd[j] : 0.0);
+    }
+  }
+}
+
+// ---- gate helpers (tangent form) ------------------------------------------------------------------------------------------
+// lane bit with a DPP partner: own += t_signed * partner, both components.  The instructions are written out because
+// the fused-operand form needs accumulator == own value; the hazard recogniser does not look inside inline asm, so the
+// wait states a DPP read of a just-written register needs (two) are spelled out: `s_nop 1` in front of every pair (the
+// second instruction of a pair reads a register the first did not write), one more behind the last pair for whatever
+// cross-lane instruction follows.  They sit in the shadow of the ~11-cycle dependent issue and cost nothing.
+template <int CTRL>
+__device__ __forceinline__ void ry_t_dpp(V2<float>& a, float ts) {
+  static_assert(CTRL == 0xB1 || CTRL == 0x4E || CTRL == 0x141 || CTRL == 0x128, "quad_perm / row_half_mirror / row_ror:8");
+  float x = a.x, y = a.y;
+  if constexpr (CTRL == 0xB1) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %0, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_fmac_f32_dpp %1, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                 : "+v"(x), "+v"(y) : "v"(ts));
+  } else if constexpr (CTRL == 0x4E) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %0, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_fmac_f32_dpp %1, %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                 : "+v"(x), "+v"(y) : "v"(ts));
+  } else if constexpr (CTRL == 0x141) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %0, %2 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_fmac_f32_dpp %1, %1, %2 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                 : "+v"(x), "+v"(y) : "v"(ts));
+  } else {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %0, %2 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_fmac_f32_dpp %1, %1, %2 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "s_nop 0"
+                 : "+v"(x), "+v"(y) : "v"(ts));
+  }
+  a = V2<float>{x, y};
+}
+template <int CTRL>
+__device__ __forceinline__ void ry_t_dpp(V2<double>& a, double ts) {
+  const double px = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(a.x), CTRL, 0xF, 0xF, true),
+                                     __builtin_amdgcn_mov_dpp(__double2loint(a.x), CTRL, 0xF, 0xF, true));
+  const double py = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(a.y), CTRL, 0xF, 0xF, true),
+                                     __builtin_amdgcn_mov_dpp(__double2loint(a.y), CTRL, 0xF, 0xF, true));
+  a = V2<double>{fma(ts, px, a.x), fma(ts, py, a.y)};
+}
+// row-crossing lane bit (4, 5): permlane swap of (re, im), the 2 x 2 on (low member, high member), swap back
+template <int Q, typename T>
+__device__ __forceinline__ void ry_t_swap(V2<T>& a, T t) {
+  T lo = a.x, hi = a.y;
+  swap_parts<Q>(lo, hi);
+  T nlo = fma(-t, hi, lo), nhi = fma(t, lo, hi);
+  swap_parts<Q>(nlo, nhi);
+  a = V2<T>{nlo, nhi};
+}
+
+// what a thread holds for one layer
+template <typename T>
+struct Quad8Layer {
+  V2<T> ph;
+  T ts[4];       // index bits 0..3, signed by this lane's bit
+  T t4, t5;
+  T k1, k2, k3;  // wave-bit exchange: partners wave^1, wave^2, wave^3
+};
+
+template <typename T, int PPT>
+__global__ __launch_bounds__(256) void dense_quad8_kernel(
+    const double* __restrict__ x, const double* __restrict__ wd, const double* __restrict__ bd,
+    const double* __restrict__ wu, const double* __restrict__ bu, double* __restrict__ y,
+    const unsigned char* __restrict__ tables, const QuadScalars d, const KScalars p) {
+  constexpr int N = 8;
+  using C = V2<T>;
+  using QT = Quad8Tables<T>;
+  using V4 = T __attribute__((ext_vector_type(4)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int lpr = p.n_blocks * p.sel_layers, layers = p.n_rounds * lpr;
+  T* s_body = reinterpret_cast<T*>(smem_raw);
+  const C* s_ph = reinterpret_cast<const C*>(s_body);
+  const T* s_un = s_body + QT::ph_elems(layers);
+  const T* s_a0 = s_un + QT::un_elems(layers);
+  C* s_slab = reinterpret_cast<C*>(smem_raw + (QT::elems(layers, p.n_rounds) * sizeof(T) + 15) / 16 * 16);
+  double* s_part = reinterpret_cast<double*>(s_slab + 2 * 4 * kWave);   // [4][16] partials of linear_down
+  double* s_part_z = s_part + 4 * 16;                                    // [2][4][16] partials of the read-out, alternating
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int llane = logical_lane(lane);
+  double* s_xs = s_part_z + 2 * 4 * 16 + wv * 16;   // [16] angles of the round, this wave's copy
+  double* s_cs = s_part_z + 3 * 4 * 16 + wv * 16;   // [16] cos(x/2); after the read-out: plain <Z_w>
+  double* s_sn = s_part_z + 4 * 4 * 16 + wv * 16;   // [16] sin(x/2)
+  const double* head = reinterpret_cast<const double*>(tables);
+  const int P = d.in_features, Q = d.out_features;
+  // the data angles reach the state only through the re-upload in front of blocks 1.. (block 0 acts on |0..0>)
+  const bool need_angles = p.n_blocks > 1;
+
+  // ---- per-launch setup: linear_up weights of this thread's pixels in registers, tables into LDS --------------------
+  double wur[PPT][N], bur[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int pix = tid + i * 256;
+#pragma unroll
+    for (int j = 0; j < N; ++j) wur[i][j] = pix < Q ? wu[(size_t)pix * N + j] : 0.0;
+    bur[i] = (bu && pix < Q) ? bu[pix] : 0.0;
+  }
+  {
+    const T* src = reinterpret_cast<const T*>(tables + kQuad8HeaderDoubles * sizeof(double));
+    const int n_t = (int)QT::elems(layers, p.n_rounds);
+    for (int i = tid; i < n_t; i += 256) s_body[i] = src[i];
+  }
+  const uint32_t kbase = ((uint32_t)wv << 6) | (uint32_t)llane;
+  T pm[8];   // +-1 by this thread's index bit
+#pragma unroll
+  for (int q = 0; q < 8; ++q) pm[q] = ((kbase >> q) & 1u) ? (T)1 : (T)-1;
+  // composite map of the next step's angles (lanes < 8 of every wave hold row `lane`)
+  double mrow[N], vrow = 0.0;
+#pragma unroll
+  for (int i = 0; i < N; ++i) mrow[i] = (need_angles && lane < N) ? head[1 + lane * N + i] : 0.0;
+  if (need_angles && lane < N) vrow = head[65 + lane];
+  auto wave_sync = [&]() {   // LDS hand-over inside the wavefront
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // a layer's data in two halves: the raw LDS reads (issued a layer ahead, at the top of the layer before), and what is
+  // derived from them (signs by this thread's index bits, k3) -- multiplies that ride in the chain's empty issue slots
+  struct Raw {
+    C ph;
+    V4 lo, hi;   // t of index bits 0..3 / 4..7
+  };
+  auto fetch_layer = [&](Raw& r, int l) {
+    r.ph = s_ph[l * 256 + tid];
+    const V4* u = reinterpret_cast<const V4*>(s_un + l * 8);
+    r.lo = u[0];
+    r.hi = u[1];
+  };
+  auto derive_layer = [&](Quad8Layer<T>& c, const Raw& r) {
+    c.ph = r.ph;
+    c.ts[0] = r.lo.x * pm[0];
+    c.ts[1] = r.lo.y * pm[1];
+    c.ts[2] = r.lo.z * pm[2];
+    c.ts[3] = r.lo.w * pm[3];
+    c.t4 = r.hi.x;
+    c.t5 = r.hi.y;
+    c.k1 = r.hi.z * pm[6];
+    c.k2 = r.hi.w * pm[7];
+    c.k3 = c.k1 * c.k2;
+  };
+  __syncthreads();
+
+  int xbuf_parity = 0, zbuf_parity = 0;
+  for (int64_t sample = blockIdx.x; sample < p.batch; sample += gridDim.x) {
+    for (int step = 0; step < d.n_steps; ++step) {
+      // ---- this step's data angles -------------------------------------------------------------------------
+      if (need_angles) {
+        if (step == 0) {
+          // linear_down on the input image (the only step that reads an image)
+          double acc[N];
+#pragma unroll
+          for (int j = 0; j < N; ++j) acc[j] = 0.0;
+#pragma unroll
+          for (int i = 0; i < PPT; ++i) {
+            const int pix = tid + i * 256;
+            const double xv = pix < P ? x[sample * d.x_ld + pix] : 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) acc[j] = fma(xv, pix < P ? wd[(size_t)j * P + pix] : 0.0, acc[j]);
+          }
+          wave_reduce8_into<double, true>(acc, lane, llane, s_part + wv * 16);
+          __syncthreads();
+          if (lane < N) {
+            const double h = s_part[lane] + s_part[16 + lane] + s_part[32 + lane] + s_part[48 + lane] +
+                             (bd ? bd[lane] : 0.0);
+            s_xs[lane] = h * p.enc_scale;
+          }
+        } else if (lane < N) {
+          // x <- net(x) without a clamp: linear_down(linear_up(z) ) = M z + v  (s_cs holds the last step's <Z>)
+          double h = vrow;
+#pragma unroll
+          for (int i = 0; i < N; ++i) h = fma(mrow[i], s_cs[i], h);
+          s_xs[lane] = h * p.enc_scale;
+        }
+      }
+      // ---- circuit rounds ------------------------------------------------------------------------------------
+      for (int round = 0; round < p.n_rounds; ++round) {
+        const int l0 = round * lpr;
+        C dx{(T)1, (T)0};
+        if (need_angles) {
+          if (lane < N) {
+            if constexpr (sizeof(T) == 4) {
+              float s, c;
+              data_sincos_f32(0.5 * s_xs[lane], &s, &c);
+              s_cs[lane] = (double)c;
+              s_sn[lane] = (double)s;
+            } else {
+              double s, c;
+              sincos(0.5 * s_xs[lane], &s, &c);
+              s_cs[lane] = c;
+              s_sn[lane] = s;
+            }
+          }
+          wave_sync();
+          T fr = 1, fi = 0;   // RZ(x) diagonal of this thread's amplitude
+#pragma unroll
+          for (int q = 0; q < N; ++q) {
+            const T c = (T)s_cs[N - 1 - q];
+            const T si = ((kbase >> q) & 1u) ? (T)s_sn[N - 1 - q] : -(T)s_sn[N - 1 - q];
+            const T nr = fr * c - fi * si;
+            fi = fr * si + fi * c;
+            fr = nr;
+          }
+          dx = C{fr, fi};
+        }
+        C a{s_a0[round * 256 + tid], (T)0};   // the round's first layer, generated
+        Quad8Layer<T> ca, cb;
+        Raw raw;
+        if (lpr > 1) {
+          fetch_layer(raw, l0 + 1);
+          derive_layer(ca, raw);
+        }
+
+        int next_upload = need_angles ? p.sel_layers : 0x7fffffff;   // first layer of block 1
+        auto layer = [&](const Quad8Layer<T>& cur, Quad8Layer<T>& nxt, int li) {
+          // the next layer's phase and tangents first: they land while this layer's chain runs, and what is derived from
+          // them (signs, k3) fills issue slots the chain leaves empty -- nothing table-related is left behind the barrier
+          // (unconditional -- the last layer re-reads its own entry -- so that the wait counters are exact on every path)
+          fetch_layer(raw, l0 + (li + 1 < lpr ? li + 1 : li));
+          __builtin_amdgcn_sched_barrier(0);
+          C phv = cur.ph;
+          if (li == next_upload) {   // block start: data re-upload (a scalar branch)
+            next_upload += p.sel_layers;
+            asm volatile("" ::: "memory");
+            phv = cmul2<T>(dx, phv, times_i<T>(phv));
+          }
+          a = cmul2<T>(phv, a, times_i<T>(a));
+          ry_t_dpp<0xB1>(a, cur.ts[0]);
+          ry_t_dpp<0x4E>(a, cur.ts[1]);
+          ry_t_dpp<0x141>(a, cur.ts[2]);
+          ry_t_dpp<0x128>(a, cur.ts[3]);
+          ry_t_swap<5, T>(a, cur.t5);
+          derive_layer(nxt, raw);   // (the reads were issued ~100 cycles ago)
+          ry_t_swap<4, T>(a, cur.t4);
+          C* buf = s_slab + (size_t)xbuf_parity * (4 * kWave);
+          xbuf_parity ^= 1;
+          buf[wv * kWave + lane] = a;
+          __syncthreads();
+          const C p1 = buf[(wv ^ 1) * kWave + lane];
+          const C p2 = buf[(wv ^ 2) * kWave + lane];
+          const C p3 = buf[(wv ^ 3) * kWave + lane];
+          const C o = __builtin_elementwise_fma(bcast<T>(cur.k1), p1, a);
+          const C t = __builtin_elementwise_fma(bcast<T>(cur.k3), p3, bcast<T>(cur.k2) * p2);
+          a = o + t;
+        };
+        int li = 1;
+        for (; li + 1 < lpr; li += 2) {
+          layer(ca, cb, li);
+          layer(cb, ca, li + 1);
+        }
+        if (li < lpr) layer(ca, cb, li);
+        // ---- <Z_w> (the ring and the RZ(omega) behind the last RY layer are diagonal) ----------------------
+        const T pr = a.x * a.x + a.y * a.y;
+        T ez[8];
+#pragma unroll
+        for (int w = 0; w < N; ++w) ez[w] = ((kbase >> (N - 1 - w)) & 1u) ? -pr : pr;
+        wave_sync();   // (this wave's readers of s_cs / s_sn are done)
+        // (two partial buffers in turn: a round without simulated layers has no barrier between one read-out's readers and
+        //  the next one's writers)
+        T* s_pz = reinterpret_cast<T*>(s_part_z + zbuf_parity * 4 * 16);
+        zbuf_parity ^= 1;
+        wave_reduce8_into<T, true>(ez, lane, llane, s_pz + wv * 16);
+        __syncthreads();
+        if (lane < N) {
+          const double e = (double)s_pz[lane] + (double)s_pz[16 + lane] + (double)s_pz[32 + lane] + (double)s_pz[48 + lane];
+          s_xs[lane] = e * p.enc_scale;   // next round's angles
+          s_cs[lane] = e;                 // plain <Z_w> for linear_up and the next step's composite
+        }
+      }
+      wave_sync();
+      double ev[N];
+#pragma unroll
+      for (int j = 0; j < N; ++j) ev[j] = s_cs[j];
+      // ---- linear_up: this step's image ---------------------------------------------------------------------
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const int pix = tid + i * 256;
+        double o = bur[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) o = fma(ev[j], wur[i][j], o);
+        if (pix < Q) y[(size_t)step * d.y_step_stride + sample * d.y_ld + pix] = o;
+      }
+    }
+  }
+}
+
+}  // namespace qiddm

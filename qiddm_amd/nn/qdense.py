@@ -84,6 +84,33 @@ class _QuantumNet(nn.Module):
             self._sampler_tables_cache = cached
         return cached[1]
 
+    def _lean_sampler_tables(self, circ, angles, lin_down, lin_up):
+        """Tables of the lean 8-qubit sampler (goal "data"), rebuilt only when the weights, the two linears or the
+        precision changed; None when that kernel does not apply (then the general sampler runs)."""
+        tensors = (angles, lin_down.weight, lin_down.bias, lin_up.weight, lin_up.bias)
+        stamp = tuple((t._version, t.data_ptr()) for t in tensors if t is not None) + \
+            (str(angles.device), _c._default_precision, circ.angles_shape)
+        cached = getattr(self, "_lean_tables_cache", None)
+        if cached is None or cached[0] != stamp:
+            if torch.cuda.is_current_stream_capturing():
+                return None                       # cannot validate inside a recording: not cached either
+            cached = (stamp, _c.dense_sample_lean_tables(circ, angles.reshape(circ.angles_shape), lin_down.weight,
+                                                         lin_down.bias, lin_up.weight, lin_up.bias))
+            self._lean_tables_cache = cached
+        return cached[1]
+
+    def _fused_sampler_launch(self, circ, flat, angles, n_steps, goal, noise_factor):
+        """n_steps loop bodies in one launch: the lean 8-qubit kernel where it applies (goal "data"), else the general
+        four-wavefront sampler."""
+        ld, lu = self.linear_down, self.linear_up
+        if goal == "data":
+            lean = self._lean_sampler_tables(circ, angles, ld, lu)
+            if lean is not None:
+                return _c.dense_sample_lean(circ, flat, ld.weight, ld.bias, lu.weight, lu.bias, n_steps, lean)
+        return _c.dense_sample(circ, flat, ld.weight, ld.bias, angles.reshape(circ.angles_shape), lu.weight, lu.bias,
+                               n_steps, post_mode=0 if goal == "data" else 1, noise_factor=noise_factor,
+                               tables=self._sampler_tables(circ, angles))
+
     # -- fused training step (SURVEY.md section 8f rank 1) -------------------------------------------------
     def _train_family(self):
         """``(circuit, linear_down, angles parameter, linear_up)`` for nets of the
@@ -301,10 +328,7 @@ class QNN_noise(_QuantumNet):
         if flat.shape[1] > 2048 or flat.shape[1] != self.linear_up.weight.shape[0]:
             return None
         try:
-            out = _c.dense_sample(circ, flat, self.linear_down.weight, self.linear_down.bias,
-                                  self.weights.reshape(circ.angles_shape), self.linear_up.weight,
-                                  self.linear_up.bias, n_steps, post_mode=0 if goal == "data" else 1,
-                                  noise_factor=noise_factor, tables=self._sampler_tables(circ, self.weights))
+            out = self._fused_sampler_launch(circ, flat, self.weights, n_steps, goal, noise_factor)
         except _capi.QiddmError as e:
             if e.code == -2:      # outside the fused sampler's range (e.g. tables beyond LDS): step by step
                 return None
@@ -508,10 +532,7 @@ class _QIDDMBase(_QuantumNet):
         circ = _c.Circuit(n_qubits=self.hidden_features, encoding="rz", imprimitive="CZ", measure="expz",
                           n_rounds=self.N, n_blocks=self.spectrum_layer, sel_layers=2)
         try:
-            out = _c.dense_sample(circ, flat, self.linear_down.weight, self.linear_down.bias, self.weights1,
-                                  self.linear_up.weight, self.linear_up.bias, n_steps,
-                                  post_mode=0 if goal == "data" else 1, noise_factor=noise_factor,
-                                  tables=self._sampler_tables(circ, self.weights1))
+            out = self._fused_sampler_launch(circ, flat, self.weights1, n_steps, goal, noise_factor)
         except _capi.QiddmError as e:
             if e.code == -2:      # outside the fused sampler's range: step by step
                 return None
