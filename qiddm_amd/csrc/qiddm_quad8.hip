@@ -42,11 +42,11 @@ qiddm::KScalars params_of(const qiddm_circuit_t* c) {
   return p;
 }
 
-template <typename T, int PPT>
+template <typename T, int PPT, bool REUP, int LPR>
 int launch_lean(const double* x, const double* wd, const double* bd, const double* wu, const double* bu, double* y,
                 const void* tables, const qiddm::QuadScalars& d, const qiddm::KScalars& p, int layers, hipStream_t st) {
   const size_t smem = qiddm::Quad8Tables<T>::lds_bytes(layers, p.n_rounds);
-  auto kern = qiddm::dense_quad8_kernel<T, PPT>;
+  auto kern = qiddm::dense_quad8_kernel<T, PPT, REUP, LPR>;
   static qiddm_capi::DeviceFlags big_lds_enabled;
   if (smem > 48 * 1024 && !big_lds_enabled.get()) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -60,6 +60,25 @@ int launch_lean(const double* x, const double* wd, const double* bd, const doubl
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "dense_quad8_kernel launch failed: %s", hipGetErrorString(e));
   return QIDDM_OK;
+}
+
+// the instantiation for this circuit: re-upload or not; layers per round compiled in for the two shapes the reference's
+// drivers use at 8 qubits (14: QNN_noise(784, 8, 14), src/mnist_exm.py:48; 12: the (8, 6, 2) LL / PL nets,
+// src/fashion_exm.py:45), a runtime count otherwise
+template <typename T>
+int dispatch_lean(const double* x, const double* wd, const double* bd, const double* wu, const double* bu, double* y,
+                  const void* tables, const qiddm::QuadScalars& d, const qiddm::KScalars& p, int layers, hipStream_t st) {
+  const bool reup = p.n_blocks > 1;
+  const int lpr = p.n_blocks * p.sel_layers;
+  if (d.in_features > 1024)
+    return reup ? launch_lean<T, 8, true, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st)
+                : launch_lean<T, 8, false, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+  if (reup) {
+    if (lpr == 12) return launch_lean<T, 4, true, 12>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+    return launch_lean<T, 4, true, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+  }
+  if (lpr == 14) return launch_lean<T, 4, false, 14>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+  return launch_lean<T, 4, false, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
 }
 
 }  // namespace
@@ -134,13 +153,10 @@ int qiddm_dense_sample_lean(const qiddm_circuit_t* c, const double* x, int64_t b
   d.post_mode = 0;
   d.n_steps = n_steps;
   d.noise_factor = 1.0;
+  d.stamps = qiddm_capi::stamp_buffer(8);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool small = features <= 1024;
-  if (c->dtype == QIDDM_F32)
-    return small ? launch_lean<float, 4>(x, w_down, b_down, w_up, b_up, y, tables, d, p, layers, st)
-                 : launch_lean<float, 8>(x, w_down, b_down, w_up, b_up, y, tables, d, p, layers, st);
-  return small ? launch_lean<double, 4>(x, w_down, b_down, w_up, b_up, y, tables, d, p, layers, st)
-               : launch_lean<double, 8>(x, w_down, b_down, w_up, b_up, y, tables, d, p, layers, st);
+  return c->dtype == QIDDM_F32 ? dispatch_lean<float>(x, w_down, b_down, w_up, b_up, y, tables, d, p, layers, st)
+                               : dispatch_lean<double>(x, w_down, b_down, w_up, b_up, y, tables, d, p, layers, st);
 }
 
 }  // extern "C"

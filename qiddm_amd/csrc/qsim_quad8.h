@@ -47,7 +47,7 @@ struct Quad8Tables {
   // LDS of dense_quad8_kernel: the tables, the double-buffered exchange slab, partial sums and per-wave angle copies
   __host__ __device__ static size_t lds_bytes(int layers, int rounds) {
     return (elems(layers, rounds) * sizeof(T) + 15) / 16 * 16 + (size_t)2 * 4 * kWave * 2 * sizeof(T) +
-           (size_t)(3 * 4 * 16 + 3 * 4 * 16) * sizeof(double);
+           (size_t)(3 * 4 * 16 + 3 * 4 * 16 + 80) * sizeof(double);
   }
 };
 
@@ -133,37 +133,30 @@ __global__ __launch_bounds__(256) void quad8_tables_kernel(const double* __restr
 }
 
 // ---- gate helpers (tangent form) ------------------------------------------------------------------------------------------
-// lane bit with a DPP partner: own += t_signed * partner, both components.  The instructions are written out because
-// the fused-operand form needs accumulator == own value; the hazard recogniser does not look inside inline asm, so the
-// wait states a DPP read of a just-written register needs (two) are spelled out: `s_nop 1` in front of every pair (the
-// second instruction of a pair reads a register the first did not write), one more behind the last pair for whatever
-// cross-lane instruction follows.  They sit in the shadow of the ~11-cycle dependent issue and cost nothing.
-template <int CTRL>
-__device__ __forceinline__ void ry_t_dpp(V2<float>& a, float ts) {
-  static_assert(CTRL == 0xB1 || CTRL == 0x4E || CTRL == 0x141 || CTRL == 0x128, "quad_perm / row_half_mirror / row_ror:8");
+// The four lane-bit gates with a DPP partner (index bits 0..3: quad_perm, quad_perm, row_half_mirror, row_ror:8):
+// own += t_signed * partner on both components, `v_fmac_f32_dpp` with accumulator == own value, in place.  Written out
+// because the fused-operand form is not reachable from the compiler, and because the hazard recogniser does not look
+// inside inline asm: a DPP read of a register needs two wait states behind the vector instruction that wrote it.  The
+// imaginary-part instruction of a gate is one of them, `s_nop 0` the other (`s_nop 1` in front: the phase multiply wrote
+// the pair; `s_nop 1` behind: a permlane swap follows).  They sit in the shadow of the ~11-cycle dependent issue.
+__device__ __forceinline__ void ry_t_dpp4(V2<float>& a, float t0, float t1, float t2, float t3) {
   float x = a.x, y = a.y;
-  if constexpr (CTRL == 0xB1) {
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f32_dpp %0, %0, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                 "v_fmac_f32_dpp %1, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-                 : "+v"(x), "+v"(y) : "v"(ts));
-  } else if constexpr (CTRL == 0x4E) {
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f32_dpp %0, %0, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                 "v_fmac_f32_dpp %1, %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-                 : "+v"(x), "+v"(y) : "v"(ts));
-  } else if constexpr (CTRL == 0x141) {
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f32_dpp %0, %0, %2 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                 "v_fmac_f32_dpp %1, %1, %2 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1"
-                 : "+v"(x), "+v"(y) : "v"(ts));
-  } else {
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f32_dpp %0, %0, %2 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                 "v_fmac_f32_dpp %1, %1, %2 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                 "s_nop 0"
-                 : "+v"(x), "+v"(y) : "v"(ts));
-  }
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f32_dpp %0, %0, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %1, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 0\n\t"
+      "v_fmac_f32_dpp %0, %0, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %1, %1, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 0\n\t"
+      "v_fmac_f32_dpp %0, %0, %4 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %1, %1, %4 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 0\n\t"
+      "v_fmac_f32_dpp %0, %0, %5 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %1, %1, %5 row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1"
+      : "+v"(x), "+v"(y)
+      : "v"(t0), "v"(t1), "v"(t2), "v"(t3));
   a = V2<float>{x, y};
 }
 template <int CTRL>
@@ -173,6 +166,12 @@ __device__ __forceinline__ void ry_t_dpp(V2<double>& a, double ts) {
   const double py = __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(a.y), CTRL, 0xF, 0xF, true),
                                      __builtin_amdgcn_mov_dpp(__double2loint(a.y), CTRL, 0xF, 0xF, true));
   a = V2<double>{fma(ts, px, a.x), fma(ts, py, a.y)};
+}
+__device__ __forceinline__ void ry_t_dpp4(V2<double>& a, double t0, double t1, double t2, double t3) {
+  ry_t_dpp<0xB1>(a, t0);
+  ry_t_dpp<0x4E>(a, t1);
+  ry_t_dpp<0x141>(a, t2);
+  ry_t_dpp<0x128>(a, t3);
 }
 // row-crossing lane bit (4, 5): permlane swap of (re, im), the 2 x 2 on (low member, high member), swap back
 template <int Q, typename T>
@@ -193,7 +192,11 @@ struct Quad8Layer {
   T k1, k2, k3;  // wave-bit exchange: partners wave^1, wave^2, wave^3
 };
 
-template <typename T, int PPT>
+// REUP: the circuit re-uploads its data angles (n_blocks > 1); without it the angles never reach the state and no
+//       angle code is compiled at all (no branch in the layer either: a taken branch costs a lone wavefront ~50 cycles).
+// LPR:  layers per round as a compile-time constant (fully unrolled layer sequence; 14 = the flagship QNN_noise(784, 8,
+//       14), 12 = the LL-style (6 blocks x 2)), or 0 for a runtime count (loop over pairs of layers).
+template <typename T, int PPT, bool REUP, int LPR>
 __global__ __launch_bounds__(256) void dense_quad8_kernel(
     const double* __restrict__ x, const double* __restrict__ wd, const double* __restrict__ bd,
     const double* __restrict__ wu, const double* __restrict__ bu, double* __restrict__ y,
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
   using QT = Quad8Tables<T>;
   using V4 = T __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int lpr = p.n_blocks * p.sel_layers, layers = p.n_rounds * lpr;
+  const int lpr = LPR > 0 ? LPR : p.n_blocks * p.sel_layers, layers = p.n_rounds * lpr;
   T* s_body = reinterpret_cast<T*>(smem_raw);
   const C* s_ph = reinterpret_cast<const C*>(s_body);
   const T* s_un = s_body + QT::ph_elems(layers);
@@ -214,12 +217,12 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int llane = logical_lane(lane);
   double* s_xs = s_part_z + 2 * 4 * 16 + wv * 16;   // [16] angles of the round, this wave's copy
-  double* s_cs = s_part_z + 3 * 4 * 16 + wv * 16;   // [16] cos(x/2); after the read-out: plain <Z_w>
-  double* s_sn = s_part_z + 4 * 4 * 16 + wv * 16;   // [16] sin(x/2)
+  double* s_cs = s_part_z + 3 * 4 * 16 + wv * 16;   // [16] cos(x/2) then sin(x/2) of the round, in T
   const double* head = reinterpret_cast<const double*>(tables);
   const int P = d.in_features, Q = d.out_features;
-  // the data angles reach the state only through the re-upload in front of blocks 1.. (block 0 acts on |0..0>)
-  const bool need_angles = p.n_blocks > 1;
+  // diagnostics (tools/stamp_lean.py): s_memtime of workgroup 0 / thread 0 in the launch's second step
+  const bool stamp = d.stamps != nullptr && blockIdx.x == 0 && tid == 0;
+  if (stamp) d.stamps[0] = __builtin_amdgcn_s_memtime();
 
   // ---- per-launch setup: linear_up weights of this thread's pixels in registers, tables into LDS --------------------
   double wur[PPT][N], bur[PPT];
@@ -227,23 +230,31 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
   for (int i = 0; i < PPT; ++i) {
     const int pix = tid + i * 256;
 #pragma unroll
-    for (int j = 0; j < N; ++j) wur[i][j] = pix < Q ? wu[(size_t)pix * N + j] : 0.0;
+    for (int j = 0; j < N; ++j) wur[i][j] = pix < Q ? wu[(size_t)pix * N + j] : 0.0;   // (zeros beyond the image)
     bur[i] = (bu && pix < Q) ? bu[pix] : 0.0;
   }
   {
-    const T* src = reinterpret_cast<const T*>(tables + kQuad8HeaderDoubles * sizeof(double));
-    const int n_t = (int)QT::elems(layers, p.n_rounds);
-    for (int i = tid; i < n_t; i += 256) s_body[i] = src[i];
+    // 16 bytes per thread and trip, four trips in flight (the element count is a multiple of four)
+    const V4* src = reinterpret_cast<const V4*>(tables + kQuad8HeaderDoubles * sizeof(double));
+    V4* dst = reinterpret_cast<V4*>(s_body);
+    const int n4 = (int)(QT::elems(layers, p.n_rounds) / 4);
+    int i = tid;
+    for (; i + 768 < n4; i += 1024) {
+      const V4 v0 = src[i], v1 = src[i + 256], v2 = src[i + 512], v3 = src[i + 768];
+      dst[i] = v0;
+      dst[i + 256] = v1;
+      dst[i + 512] = v2;
+      dst[i + 768] = v3;
+    }
+    for (; i < n4; i += 256) dst[i] = src[i];
   }
   const uint32_t kbase = ((uint32_t)wv << 6) | (uint32_t)llane;
   T pm[8];   // +-1 by this thread's index bit
 #pragma unroll
   for (int q = 0; q < 8; ++q) pm[q] = ((kbase >> q) & 1u) ? (T)1 : (T)-1;
-  // composite map of the next step's angles (lanes < 8 of every wave hold row `lane`)
-  double mrow[N], vrow = 0.0;
-#pragma unroll
-  for (int i = 0; i < N; ++i) mrow[i] = (need_angles && lane < N) ? head[1 + lane * N + i] : 0.0;
-  if (need_angles && lane < N) vrow = head[65 + lane];
+  // composite map of the next step's angles (M row-major, then v) in LDS
+  double* s_map = s_part_z + 5 * 4 * 16;   // [72]
+  if (REUP && tid < 72) s_map[tid] = head[1 + tid];
   auto wave_sync = [&]() {   // LDS hand-over inside the wavefront
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -261,32 +272,29 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
     r.lo = u[0];
     r.hi = u[1];
   };
-  auto derive_layer = [&](Quad8Layer<T>& c, const Raw& r) {
-    c.ph = r.ph;
-    c.ts[0] = r.lo.x * pm[0];
-    c.ts[1] = r.lo.y * pm[1];
-    c.ts[2] = r.lo.z * pm[2];
-    c.ts[3] = r.lo.w * pm[3];
-    c.t4 = r.hi.x;
-    c.t5 = r.hi.y;
-    c.k1 = r.hi.z * pm[6];
-    c.k2 = r.hi.w * pm[7];
-    c.k3 = c.k1 * c.k2;
-  };
+  // every global load of the setup has landed before the loops: the steps' stores then never wait for a load counter
+  // (loads and stores share it, in order -- a wait for a setup load inside the loop is a wait for the previous store)
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
   __syncthreads();
+  if (stamp) d.stamps[1] = __builtin_amdgcn_s_memtime();
 
   int xbuf_parity = 0, zbuf_parity = 0;
+  double ev[N];   // <Z_w> of the last round: linear_up's input and the next step's composite input
+#pragma unroll
+  for (int j = 0; j < N; ++j) ev[j] = 0.0;
   for (int64_t sample = blockIdx.x; sample < p.batch; sample += gridDim.x) {
     for (int step = 0; step < d.n_steps; ++step) {
+      const bool st = stamp && step == 1;
+      if (st) d.stamps[2] = __builtin_amdgcn_s_memtime();
       // ---- this step's data angles -------------------------------------------------------------------------
-      if (need_angles) {
+      if constexpr (REUP) {
         if (step == 0) {
           // linear_down on the input image (the only step that reads an image)
           double acc[N];
 #pragma unroll
           for (int j = 0; j < N; ++j) acc[j] = 0.0;
-#pragma unroll
-          for (int i = 0; i < PPT; ++i) {
+#pragma unroll 1
+          for (int i = 0; i < PPT; ++i) {     // (pixel by pixel: once per launch and sample, keep its registers few)
             const int pix = tid + i * 256;
             const double xv = pix < P ? x[sample * d.x_ld + pix] : 0.0;
 #pragma unroll
@@ -299,72 +307,94 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
                              (bd ? bd[lane] : 0.0);
             s_xs[lane] = h * p.enc_scale;
           }
-        } else if (lane < N) {
-          // x <- net(x) without a clamp: linear_down(linear_up(z) ) = M z + v  (s_cs holds the last step's <Z>)
-          double h = vrow;
+        } else {
+          // x <- net(x) without a clamp: linear_down(linear_up(z)) = M z + v, z = the last step's <Z> (in registers);
+          // lane j < 8 takes row j (every lane computes a row -- j = lane & 7 -- so nothing branches), two chains of four
+          const double* mr = s_map + (lane & 7) * N;
+          double h0 = s_map[64 + (lane & 7)], h1 = 0.0;
 #pragma unroll
-          for (int i = 0; i < N; ++i) h = fma(mrow[i], s_cs[i], h);
-          s_xs[lane] = h * p.enc_scale;
+          for (int i = 0; i < N; i += 2) {
+            h0 = fma(mr[i], ev[i], h0);
+            h1 = fma(mr[i + 1], ev[i + 1], h1);
+          }
+          if (lane < N) s_xs[lane] = (h0 + h1) * p.enc_scale;
         }
       }
+      if (st) d.stamps[3] = __builtin_amdgcn_s_memtime();
       // ---- circuit rounds ------------------------------------------------------------------------------------
       for (int round = 0; round < p.n_rounds; ++round) {
         const int l0 = round * lpr;
         C dx{(T)1, (T)0};
-        if (need_angles) {
+        if constexpr (REUP) {
+          T* s_cst = reinterpret_cast<T*>(s_cs);   // [8] cos(x_w / 2), then [8] sin(x_w / 2): this wave's copy
           if (lane < N) {
             if constexpr (sizeof(T) == 4) {
               float s, c;
               data_sincos_f32(0.5 * s_xs[lane], &s, &c);
-              s_cs[lane] = (double)c;
-              s_sn[lane] = (double)s;
+              s_cst[lane] = c;
+              s_cst[N + lane] = s;
             } else {
               double s, c;
               sincos(0.5 * s_xs[lane], &s, &c);
-              s_cs[lane] = c;
-              s_sn[lane] = s;
+              s_cst[lane] = c;
+              s_cst[N + lane] = s;
             }
           }
           wave_sync();
-          T fr = 1, fi = 0;   // RZ(x) diagonal of this thread's amplitude
+          // RZ(x) diagonal of this thread's amplitude, prod_q (cos + i sigma_q sin)(x_{7-q} / 2) with sigma = +-1 by the
+          // thread's index bit: a tree of complex products (depth 3), not a chain of eight
+          const V4* cs4 = reinterpret_cast<const V4*>(s_cst);
+          const V4 c_lo = cs4[0], c_hi = cs4[1], s_lo = cs4[2], s_hi = cs4[3];   // wires 0..3 / 4..7
+          const T cw[8] = {c_lo.x, c_lo.y, c_lo.z, c_lo.w, c_hi.x, c_hi.y, c_hi.z, c_hi.w};
+          const T sw[8] = {s_lo.x, s_lo.y, s_lo.z, s_lo.w, s_hi.x, s_hi.y, s_hi.z, s_hi.w};
+          C z[8];
 #pragma unroll
-          for (int q = 0; q < N; ++q) {
-            const T c = (T)s_cs[N - 1 - q];
-            const T si = ((kbase >> q) & 1u) ? (T)s_sn[N - 1 - q] : -(T)s_sn[N - 1 - q];
-            const T nr = fr * c - fi * si;
-            fi = fr * si + fi * c;
-            fr = nr;
-          }
-          dx = C{fr, fi};
+          for (int q = 0; q < N; ++q) z[q] = C{cw[N - 1 - q], sw[N - 1 - q] * pm[q]};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) z[q] = cmul2<T>(z[q], z[q + 4], times_i<T>(z[q + 4]));
+          z[0] = cmul2<T>(z[0], z[2], times_i<T>(z[2]));
+          z[1] = cmul2<T>(z[1], z[3], times_i<T>(z[3]));
+          dx = cmul2<T>(z[0], z[1], times_i<T>(z[1]));
         }
+        if (st && round == 0) d.stamps[7] = __builtin_amdgcn_s_memtime();
         C a{s_a0[round * 256 + tid], (T)0};   // the round's first layer, generated
         Quad8Layer<T> ca, cb;
         Raw raw;
+        int next_upload = REUP ? p.sel_layers : 0x7fffffff;   // first layer of block 1
+        // what layer li will multiply the state by: its phase entry, times the data diagonal at a block start (selected,
+        // not branched on: the product rides in empty issue slots a layer ahead)
+        auto derive_layer = [&](Quad8Layer<T>& c, const Raw& r, int li) {
+          c.ph = r.ph;
+          if constexpr (REUP) {
+            const bool up = li == next_upload;
+            if (up) next_upload += p.sel_layers;     // (scalar select, no branch)
+            const C dxs = C{up ? dx.x : (T)1, up ? dx.y : (T)0};
+            c.ph = cmul2<T>(dxs, r.ph, times_i<T>(r.ph));
+          }
+          c.ts[0] = r.lo.x * pm[0];
+          c.ts[1] = r.lo.y * pm[1];
+          c.ts[2] = r.lo.z * pm[2];
+          c.ts[3] = r.lo.w * pm[3];
+          c.t4 = r.hi.x;
+          c.t5 = r.hi.y;
+          c.k1 = r.hi.z * pm[6];
+          c.k2 = r.hi.w * pm[7];
+          c.k3 = c.k1 * c.k2;
+        };
         if (lpr > 1) {
           fetch_layer(raw, l0 + 1);
-          derive_layer(ca, raw);
+          derive_layer(ca, raw, 1);
         }
-
-        int next_upload = need_angles ? p.sel_layers : 0x7fffffff;   // first layer of block 1
         auto layer = [&](const Quad8Layer<T>& cur, Quad8Layer<T>& nxt, int li) {
           // the next layer's phase and tangents first: they land while this layer's chain runs, and what is derived from
-          // them (signs, k3) fills issue slots the chain leaves empty -- nothing table-related is left behind the barrier
+          // them fills issue slots the chain leaves empty -- nothing table-related is left behind the barrier
           // (unconditional -- the last layer re-reads its own entry -- so that the wait counters are exact on every path)
           fetch_layer(raw, l0 + (li + 1 < lpr ? li + 1 : li));
           __builtin_amdgcn_sched_barrier(0);
-          C phv = cur.ph;
-          if (li == next_upload) {   // block start: data re-upload (a scalar branch)
-            next_upload += p.sel_layers;
-            asm volatile("" ::: "memory");
-            phv = cmul2<T>(dx, phv, times_i<T>(phv));
-          }
-          a = cmul2<T>(phv, a, times_i<T>(a));
-          ry_t_dpp<0xB1>(a, cur.ts[0]);
-          ry_t_dpp<0x4E>(a, cur.ts[1]);
-          ry_t_dpp<0x141>(a, cur.ts[2]);
-          ry_t_dpp<0x128>(a, cur.ts[3]);
+          a = cmul2<T>(cur.ph, a, times_i<T>(a));
+          ry_t_dpp4(a, cur.ts[0], cur.ts[1], cur.ts[2], cur.ts[3]);
           ry_t_swap<5, T>(a, cur.t5);
-          derive_layer(nxt, raw);   // (the reads were issued ~100 cycles ago)
+          derive_layer(nxt, raw, li + 1);   // (the reads were issued ~100 cycles ago)
           ry_t_swap<4, T>(a, cur.t4);
           C* buf = s_slab + (size_t)xbuf_parity * (4 * kWave);
           xbuf_parity ^= 1;
@@ -377,43 +407,85 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
           const C t = __builtin_elementwise_fma(bcast<T>(cur.k3), p3, bcast<T>(cur.k2) * p2);
           a = o + t;
         };
-        int li = 1;
-        for (; li + 1 < lpr; li += 2) {
-          layer(ca, cb, li);
-          layer(cb, ca, li + 1);
+        if constexpr (LPR > 0) {
+#pragma unroll
+          for (int li = 1; li + 1 < LPR; li += 2) {
+            layer(ca, cb, li);
+            layer(cb, ca, li + 1);
+          }
+          if constexpr (LPR > 1 && (LPR - 1) % 2 == 1) layer(ca, cb, LPR - 1);
+        } else {
+          int li = 1;
+          for (; li + 1 < lpr; li += 2) {
+            layer(ca, cb, li);
+            layer(cb, ca, li + 1);
+          }
+          if (li < lpr) layer(ca, cb, li);
         }
-        if (li < lpr) layer(ca, cb, li);
+        if (st && round == 0) d.stamps[4] = __builtin_amdgcn_s_memtime();
         // ---- <Z_w> (the ring and the RZ(omega) behind the last RY layer are diagonal) ----------------------
         const T pr = a.x * a.x + a.y * a.y;
         T ez[8];
 #pragma unroll
         for (int w = 0; w < N; ++w) ez[w] = ((kbase >> (N - 1 - w)) & 1u) ? -pr : pr;
-        wave_sync();   // (this wave's readers of s_cs / s_sn are done)
         // (two partial buffers in turn: a round without simulated layers has no barrier between one read-out's readers and
         //  the next one's writers)
         T* s_pz = reinterpret_cast<T*>(s_part_z + zbuf_parity * 4 * 16);
         zbuf_parity ^= 1;
         wave_reduce8_into<T, true>(ez, lane, llane, s_pz + wv * 16);
         __syncthreads();
-        if (lane < N) {
-          const double e = (double)s_pz[lane] + (double)s_pz[16 + lane] + (double)s_pz[32 + lane] + (double)s_pz[48 + lane];
-          s_xs[lane] = e * p.enc_scale;   // next round's angles
-          s_cs[lane] = e;                 // plain <Z_w> for linear_up and the next step's composite
+        // every thread adds the four waves' partials itself (eight broadcast reads, no second LDS round trip), pairwise,
+        // in the engine's precision; float64 from there on
+        {
+          const V4* pz = reinterpret_cast<const V4*>(s_pz);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const V4 q = (pz[h] + pz[4 + h]) + (pz[8 + h] + pz[12 + h]);
+            ev[4 * h + 0] = (double)q.x;
+            ev[4 * h + 1] = (double)q.y;
+            ev[4 * h + 2] = (double)q.z;
+            ev[4 * h + 3] = (double)q.w;
+          }
+        }
+        if constexpr (REUP) {
+          if (round + 1 < p.n_rounds) {   // next round's angles: lane j < 8 takes <Z_j> (a select chain, no indexing)
+            double e = ev[0];
+#pragma unroll
+            for (int j = 1; j < N; ++j) e = lane == j ? ev[j] : e;
+            if (lane < N) s_xs[lane] = e * p.enc_scale;
+          }
         }
       }
-      wave_sync();
-      double ev[N];
+      if (st) d.stamps[5] = __builtin_amdgcn_s_memtime();
+      // ---- linear_up: this step's image.  The pixels of a thread advance together, each as two partial sums: eight
+      //      independent chains of four (a float64 fma waits ~20 cycles on its predecessor) ---------------------------
+      double o0[PPT], o1[PPT];
 #pragma unroll
-      for (int j = 0; j < N; ++j) ev[j] = s_cs[j];
-      // ---- linear_up: this step's image ---------------------------------------------------------------------
+      for (int i = 0; i < PPT; ++i) {
+        o0[i] = bur[i];
+        o1[i] = 0.0;
+      }
+#pragma unroll
+      for (int j = 0; j < N; j += 2) {
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+          o0[i] = fma(ev[j], wur[i][j], o0[i]);
+          o1[i] = fma(ev[j + 1], wur[i][j + 1], o1[i]);
+        }
+      }
+      double* yrow = y + (size_t)step * d.y_step_stride + sample * d.y_ld;
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        o0[i] += o1[i];
+        asm volatile("" : "+v"(o0[i]));   // (keeps the sums out of the stores' predicated blocks: all of them advance together)
+      }
 #pragma unroll
       for (int i = 0; i < PPT; ++i) {
         const int pix = tid + i * 256;
-        double o = bur[i];
-#pragma unroll
-        for (int j = 0; j < N; ++j) o = fma(ev[j], wur[i][j], o);
-        if (pix < Q) y[(size_t)step * d.y_step_stride + sample * d.y_ld + pix] = o;
+        if (Q >= 256 * (i + 1)) yrow[pix] = o0[i];   // whole group of 256 pixels inside the image: a scalar test
+        else if (pix < Q) yrow[pix] = o0[i];
       }
+      if (st) d.stamps[6] = __builtin_amdgcn_s_memtime();
     }
   }
 }
