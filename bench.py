@@ -100,12 +100,24 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MI
 VALU_PEAK_TF = 157.3           # f32 vector peak (= the f32 MFMA peak), same guide
 N_QUBITS, QDEPTH, IMG = 8, 14, 28
 MIN_TIMED_S = 0.05
-HEADLINE_KERNEL = "qiddm::dense_quad_kernel<{}, 8, 4>"
+HEADLINE_KERNEL = "qiddm::dense_lean_kernel<{}, 8, 4, false, 14>"
 TRAFFIC_PROFILE = "profiles/r02c/bench_pmc_traffic.json"     # FETCH_SIZE / WRITE_SIZE passes of the driver's command
-HEADLINE_NOTE = ("latency-bound at batch 256: one sample per CU, one wavefront per SIMD, every layer a dependent "
-                 "chain of cross-lane moves. All 14 layers of every step are computed: the first one acts on "
-                 "|0..0> and its result (a real product state) is generated per amplitude instead of simulated "
-                 "gate by gate -- exact for every input and weight; executed_flop counts it as n multiplies")
+HEADLINE_NOTE = ("latency-bound at batch 256: one sample per CU, one wavefront per SIMD, and a layer is ONE dependent chain "
+                 "(every gate acts on the same 256 amplitudes): ~11 cycles per dependent vector instruction for a lone "
+                 "wavefront + ~230 for the LDS exchange of the two wave-bit gates (tools/ubench/). All 14 layers of every "
+                 "step are computed (the first acts on |0..0>: a real product state, tabulated per weights); RY gates run in "
+                 "tangent form, one fused cross-lane multiply-add each (4 flop per amplitude and gate instead of 6: "
+                 "`executed_flop`; `standard_form_flop` is the round-2 count of the same circuit). linear_down is not "
+                 "evaluated: its output enters this circuit only as RZ on |0..0>, a global phase (finding F2) -- for nets that "
+                 "re-upload it is composed with linear_up into an n x n map of the previous step's <Z>")
+
+
+def lean_flop(n, layers_per_round, rounds, pixels, reupload):
+    """Executed flop per sample and denoise step of the lean sampler (qsim_lean.h): per amplitude and SIMULATED layer one
+    complex multiply (6) + n tangent-form RYs (one multiply-add on each of re / im: 4); per round the read-out (|a|^2: 3,
+    n signed sums: n); linear_up (2 P n); the n x n composite of the next step's angles where the circuit re-uploads."""
+    d = 1 << n
+    return rounds * ((layers_per_round - 1) * d * (6 + 4 * n) + d * (3 + n)) + 2 * pixels * n + (2 * n * n if reupload else 0)
 
 
 def init_dist(args):
@@ -364,7 +376,7 @@ def f64_timed(dev, x0, args, spl, world):
     total = args.steps * repeats
     per_step = elapsed / total
     images = world * x0.shape[0] / per_step
-    flop = dense_flop(N_QUBITS, QDEPTH, 1, IMG * IMG)
+    flop = lean_flop(N_QUBITS, QDEPTH, 1, IMG * IMG, False)
     tf = flop * x0.shape[0] * kspl / (us * 1e-6) / 1e12
     return {"dtype": "f64", "kernel": HEADLINE_KERNEL.format("double"), "steps_per_launch": kspl,
             "ms_per_step": per_step * 1e3, "timed_region_s": elapsed, "repeats": repeats,
@@ -440,12 +452,15 @@ def secondary_dense_samplers(dev, out):
     each with a small roofline block for its launch (15 steps per launch; HIP events)."""
     from qiddm_amd import models, nn, noise
     cases = (
-        # tag, ctor, batch, image side, gates/sample, n, layers per round, rounds
-        ("QIDDM_LL_noise(784,8,6,2)", lambda: nn.QIDDM_LL_noise(IMG * IMG, 8, 6, 2), 256, IMG, 480, 8, 12, 2),   # src/fashion_exm.py:45 (LL form)
-        ("QIDDM_LL_noise(784,6,14,2)", lambda: nn.QIDDM_LL_noise(IMG * IMG, 6, 14, 2), 256, IMG, 840, 6, 28, 2),  # src/mnist_exm.py:46
-        ("C1_QNN_noise(64,4,2)_b32", lambda: nn.QNN_noise(64, 4, 2), 32, 8, 20, 4, 2, 1),                        # src/mnist_noise.py:49
+        # tag, ctor, batch, image side, gates/sample, n, layers per round, rounds, kernel, executed flop per sample-step
+        ("QIDDM_LL_noise(784,8,6,2)", lambda: nn.QIDDM_LL_noise(IMG * IMG, 8, 6, 2), 256, IMG, 480,          # src/fashion_exm.py:45 (LL form)
+         "qiddm::dense_lean_kernel<float, 8, 4, true, 12>", lean_flop(8, 12, 2, IMG * IMG, True)),
+        ("QIDDM_LL_noise(784,6,14,2)", lambda: nn.QIDDM_LL_noise(IMG * IMG, 6, 14, 2), 256, IMG, 840,        # src/mnist_exm.py:46
+         "qiddm::dense_lean_kernel<float, 6, 4, true, 28>", lean_flop(6, 28, 2, IMG * IMG, True)),
+        ("C1_QNN_noise(64,4,2)_b32", lambda: nn.QNN_noise(64, 4, 2), 32, 8, 20,                              # src/mnist_noise.py:49
+         "qiddm::dense_quad_kernel<float, 4, 4>", dense_flop(4, 2, 1, 64)),
     )
-    for tag, ctor, batch, side, gates, n, lpr, rounds in cases:
+    for tag, ctor, batch, side, gates, kernel, flop in cases:
         try:
             torch.manual_seed(42)
             net = ctor().to(dev, dtype=torch.double).eval()
@@ -459,8 +474,7 @@ def secondary_dense_samplers(dev, out):
             out[f"gate_apps_per_s_{tag}"] = batch * gates / t
             with torch.no_grad():
                 us = _graph_event_us(lambda: d.denoise_steps(x, 15))
-            out[f"roofline_{tag}"] = _valu_block(dense_flop(n, lpr, rounds, side * side) * batch * 15, us,
-                                                 f"qiddm::dense_quad_kernel<float, {n}, 4>",
+            out[f"roofline_{tag}"] = _valu_block(flop * batch * 15, us, kernel,
                                                  "15 denoise steps per launch; latency-bound like the headline")
         except Exception as e:  # pragma: no cover
             out[f"error_{tag}"] = repr(e)
@@ -793,7 +807,8 @@ def main(argv=None):
         g_per_sample = circ.gate_count()
         alg_bytes = circ.algorithmic_bytes_per_sample("f32") * args.batch * kspl   # per launch
         hbm_eq = alg_bytes / (kern_us * 1e-6) / 1e9
-        flop = dense_flop(N_QUBITS, QDEPTH, 1, IMG * IMG)         # what the kernel executes (folded tables)
+        flop = lean_flop(N_QUBITS, QDEPTH, 1, IMG * IMG, False)   # what the kernel executes (tangent-form layers)
+        std_flop = dense_flop(N_QUBITS, QDEPTH, 1, IMG * IMG)     # the same circuit in the (c, s) form of round 2
         valu_tf = flop * args.batch * kspl / (kern_us * 1e-6) / 1e12
         io_bytes = (kspl + 1) * args.batch * IMG * IMG * 8        # first image in + one image out per step (exact)
         result = {
@@ -835,6 +850,8 @@ def main(argv=None):
                 "kernel_avg_us": kern_us,
                 "kernel_us_per_step": kern_us / kspl,
                 "executed_flop_per_sample_step": flop,
+                "standard_form_flop_per_sample_step": std_flop,
+                "achieved_standard_form": std_flop * args.batch * kspl / (kern_us * 1e-6) / 1e12,
                 "hbm_physical": {"io_bytes_per_launch": io_bytes, "GBps": io_bytes / (kern_us * 1e-6) / 1e9,
                                  "frac_of_peak": io_bytes / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                  "note": "images in/out only (exact count); weights and tables come from L2. The measured "

@@ -244,10 +244,10 @@ int qiddm_dense_sample(const qiddm_circuit_t *circ, const double *x, int64_t bat
 int64_t qiddm_dense_sample_tables_bytes(const qiddm_circuit_t *circ);
 int qiddm_dense_sample_prepare(const qiddm_circuit_t *circ, const double *angles, void *tables, void *stream);
 
-/* ---- lean sampling loop of the 8-qubit dense nets (qsim_quad8.h) --------------------------------------------
+/* ---- lean sampling loop of the 8- and 6-qubit dense nets (qsim_lean.h) --------------------------------------------
  * The same n_steps bodies of Diffusion.sample for prediction_goal "data" (post_mode 0: x <- net(x), reference
- * src/models.py:127-129) on 8 wires / CZ rings / RZ encoding / <Z>, with every RY in tangent form (one fused
- * cross-lane multiply-add per gate) and linear_down composed with linear_up into an 8 x 8 map of the previous step's
+ * src/models.py:127-129) on 8 or 6 wires / CZ rings / RZ encoding / <Z>, with every RY in tangent form (one fused
+ * cross-lane multiply-add per gate) and linear_down composed with linear_up into an n x n map of the previous step's
  * <Z> (W_down is only read for the first step, and not at all when the circuit has one block per round: the data
  * angles are then a global phase).  Tables: qiddm_dense_sample_lean_tables_bytes(circ) bytes, written once per
  * weights by _prepare (angles AND the two linears); _check synchronises the stream and returns 1 when the tables are

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libqiddm_hip.so")
 SOURCES = ["qiddm_capi.hip", "qiddm_train.hip", "qiddm_qconv.hip", "qiddm_mixed.hip", "qiddm_norm.hip",
-           "qiddm_wide.hip", "qiddm_cz10.hip", "qiddm_quad8.hip"]
+           "qiddm_wide.hip", "qiddm_cz10.hip", "qiddm_lean.hip"]
 OBJ_DIR = os.path.join(LIB_DIR, "obj")
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC"]
 

@@ -320,18 +320,19 @@ _LEAN_SAMPLER = os.environ.get("QIDDM_NO_LEAN_SAMPLER", "0") != "1"
 
 
 def dense_sample_lean_tables(circ: Circuit, angles, w_down, b_down, w_up, b_up, precision: str | None = None):
-    """Tables of the lean sampling loop of the 8-qubit dense nets (``qiddm_dense_sample_lean_prepare``: tangent-form
-    layers + the 8 x 8 map ``W_down W_up`` of the next step's angles), or None when the circuit is outside that
+    """Tables of the lean sampling loop of the 8- and 6-qubit dense nets (``qiddm_dense_sample_lean_prepare``: tangent-form
+    layers + the n x n map ``W_down W_up`` of the next step's angles), or None when the circuit is outside that
     kernel's family, the weights are outside the tangent form's range (``qiddm_dense_sample_lean_check``), or a HIP
     graph is being captured (the check reads one number back: build the tables once before recording)."""
-    if not _LEAN_SAMPLER or circ.n_qubits != 8 or circ.encoding != "rz" or circ.imprimitive != "CZ" \
+    n = circ.n_qubits
+    if not _LEAN_SAMPLER or n not in (6, 8) or circ.encoding != "rz" or circ.imprimitive != "CZ" \
             or circ.measure != "expz" or torch.cuda.is_current_stream_capturing():
         return None
     precision = precision or _default_precision
     device = angles.device
     ang = _as_f64(angles.detach(), device)
     wd, bd, wu, bu = (_as_f64(t, device) for t in (w_down, b_down, w_up, b_up))
-    if tuple(ang.shape) != circ.angles_shape or wd.shape[0] != 8 or wu.shape != (wd.shape[1], 8) or wd.shape[1] > 2048:
+    if tuple(ang.shape) != circ.angles_shape or wd.shape[0] != n or wu.shape != (wd.shape[1], n) or wd.shape[1] > 2048:
         return None
     lib = _capi.lib()
     cs = circ.c_struct(precision)

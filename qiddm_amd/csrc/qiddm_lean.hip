@@ -1,4 +1,4 @@
-// qiddm_quad8.hip -- C entry points of the lean sampling loop of the 8-qubit dense nets (qsim_quad8.h):
+// qiddm_quad8.hip -- C entry points of the lean sampling loop of the 8-qubit dense nets (qsim_lean.h):
 // qiddm_dense_sample_lean_tables_bytes / _prepare / _check / qiddm_dense_sample_lean (include/qiddm_hip.h).
 #include "capi_common.h"
 
@@ -6,22 +6,34 @@
 
 #include <cstring>
 
-#include "qsim_quad8.h"
+#include "qsim_lean.h"
 
 namespace {
 
 using qiddm_capi::fail;
 using qiddm_capi::kMaxLds;
 
-// the family the lean kernel is written for: 8 wires, RZ data encoding, CZ rings, <Z> read-out
+template <typename T>
+size_t lean_lds(int n, int layers, int rounds) {
+  return n == 8 ? qiddm::LeanTables<T, 8>::lds_bytes(layers, rounds) : qiddm::LeanTables<T, 6>::lds_bytes(layers, rounds);
+}
+template <typename T>
+size_t lean_bytes(int n, int layers, int rounds) {
+  return n == 8 ? qiddm::LeanTables<T, 8>::bytes(layers, rounds) : qiddm::LeanTables<T, 6>::bytes(layers, rounds);
+}
+
+// the family the lean kernel is written for: 8 or 6 wires, RZ data encoding, CZ rings, <Z> read-out
 int lean_layers(const qiddm_circuit_t* c) {
-  if (c->n_qubits != 8 || c->imprimitive != QIDDM_IMP_CZ || c->encoding != QIDDM_ENC_RZ || c->measure != QIDDM_MEAS_EXPZ)
-    return fail(QIDDM_ERR_UNSUPPORTED, "lean sampling loop: 8 qubits, CZ rings, RZ encoding, <Z> read-out only");
+  if ((c->n_qubits != 8 && c->n_qubits != 6) || c->imprimitive != QIDDM_IMP_CZ || c->encoding != QIDDM_ENC_RZ ||
+      c->measure != QIDDM_MEAS_EXPZ)
+    return fail(QIDDM_ERR_UNSUPPORTED, "lean sampling loop: 6 or 8 qubits, CZ rings, RZ encoding, <Z> read-out only");
   const int64_t layers = (int64_t)c->n_rounds * c->n_blocks * c->sel_layers;
-  const size_t lds = c->dtype == QIDDM_F32 ? qiddm::Quad8Tables<float>::lds_bytes((int)layers, c->n_rounds)
-                                           : qiddm::Quad8Tables<double>::lds_bytes((int)layers, c->n_rounds);
-  if (layers > 128 || lds > kMaxLds)
-    return fail(QIDDM_ERR_UNSUPPORTED, "lean sampling loop: %lld layers need %zu B of LDS (limit %zu, 128 layers)",
+  if (layers > 128)
+    return fail(QIDDM_ERR_UNSUPPORTED, "lean sampling loop: %lld layers (limit 128)", (long long)layers);
+  const size_t lds = c->dtype == QIDDM_F32 ? lean_lds<float>(c->n_qubits, (int)layers, c->n_rounds)
+                                           : lean_lds<double>(c->n_qubits, (int)layers, c->n_rounds);
+  if (lds > kMaxLds)
+    return fail(QIDDM_ERR_UNSUPPORTED, "lean sampling loop: %lld layers need %zu B of LDS (limit %zu)",
                 (long long)layers, lds, kMaxLds);
   return (int)layers;
 }
@@ -42,11 +54,11 @@ qiddm::KScalars params_of(const qiddm_circuit_t* c) {
   return p;
 }
 
-template <typename T, int PPT, bool REUP, int LPR>
+template <typename T, int N, int PPT, bool REUP, int LPR>
 int launch_lean(const double* x, const double* wd, const double* bd, const double* wu, const double* bu, double* y,
                 const void* tables, const qiddm::QuadScalars& d, const qiddm::KScalars& p, int layers, hipStream_t st) {
-  const size_t smem = qiddm::Quad8Tables<T>::lds_bytes(layers, p.n_rounds);
-  auto kern = qiddm::dense_quad8_kernel<T, PPT, REUP, LPR>;
+  const size_t smem = qiddm::LeanTables<T, N>::lds_bytes(layers, p.n_rounds);
+  auto kern = qiddm::dense_lean_kernel<T, N, PPT, REUP, LPR>;
   static qiddm_capi::DeviceFlags big_lds_enabled;
   if (smem > 48 * 1024 && !big_lds_enabled.get()) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -58,27 +70,35 @@ int launch_lean(const double* x, const double* wd, const double* bd, const doubl
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, st, x, wd, bd, wu, bu, y,
                      static_cast<const unsigned char*>(tables), d, p);
   const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "dense_quad8_kernel launch failed: %s", hipGetErrorString(e));
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "dense_lean_kernel launch failed: %s", hipGetErrorString(e));
   return QIDDM_OK;
 }
 
-// the instantiation for this circuit: re-upload or not; layers per round compiled in for the two shapes the reference's
-// drivers use at 8 qubits (14: QNN_noise(784, 8, 14), src/mnist_exm.py:48; 12: the (8, 6, 2) LL / PL nets,
-// src/fashion_exm.py:45), a runtime count otherwise
-template <typename T>
-int dispatch_lean(const double* x, const double* wd, const double* bd, const double* wu, const double* bu, double* y,
-                  const void* tables, const qiddm::QuadScalars& d, const qiddm::KScalars& p, int layers, hipStream_t st) {
+// the instantiation for this circuit: re-upload or not; layers per round compiled in for the shapes the reference's
+// drivers use (src/mnist_exm.py:46-48, src/fashion_exm.py:45) -- 8 qubits: 14 (QNN_noise(784, 8, 14)) and 12 (the
+// (8, 6, 2) LL / PL nets); 6 qubits: 28 (QIDDM_LL_noise(784, 6, 14, 2), the MNIST default) and 14 -- a runtime count
+// otherwise
+template <typename T, int N>
+int dispatch_lean_n(const double* x, const double* wd, const double* bd, const double* wu, const double* bu, double* y,
+                    const void* tables, const qiddm::QuadScalars& d, const qiddm::KScalars& p, int layers, hipStream_t st) {
   const bool reup = p.n_blocks > 1;
   const int lpr = p.n_blocks * p.sel_layers;
+  constexpr int kReupLpr = N == 8 ? 12 : 28;
   if (d.in_features > 1024)
-    return reup ? launch_lean<T, 8, true, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st)
-                : launch_lean<T, 8, false, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+    return reup ? launch_lean<T, N, 8, true, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st)
+                : launch_lean<T, N, 8, false, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
   if (reup) {
-    if (lpr == 12) return launch_lean<T, 4, true, 12>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
-    return launch_lean<T, 4, true, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+    if (lpr == kReupLpr) return launch_lean<T, N, 4, true, kReupLpr>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+    return launch_lean<T, N, 4, true, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
   }
-  if (lpr == 14) return launch_lean<T, 4, false, 14>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
-  return launch_lean<T, 4, false, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+  if (lpr == 14) return launch_lean<T, N, 4, false, 14>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+  return launch_lean<T, N, 4, false, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+}
+template <typename T>
+int dispatch_lean(int n, const double* x, const double* wd, const double* bd, const double* wu, const double* bu, double* y,
+                  const void* tables, const qiddm::QuadScalars& d, const qiddm::KScalars& p, int layers, hipStream_t st) {
+  return n == 8 ? dispatch_lean_n<T, 8>(x, wd, bd, wu, bu, y, tables, d, p, layers, st)
+                : dispatch_lean_n<T, 6>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
 }
 
 }  // namespace
@@ -90,8 +110,8 @@ int64_t qiddm_dense_sample_lean_tables_bytes(const qiddm_circuit_t* c) {
   if (rc != QIDDM_OK) return rc;
   const int layers = lean_layers(c);
   if (layers < 0) return layers;
-  return (int64_t)(c->dtype == QIDDM_F32 ? qiddm::Quad8Tables<float>::bytes(layers, c->n_rounds)
-                                         : qiddm::Quad8Tables<double>::bytes(layers, c->n_rounds));
+  return (int64_t)(c->dtype == QIDDM_F32 ? lean_bytes<float>(c->n_qubits, layers, c->n_rounds)
+                                         : lean_bytes<double>(c->n_qubits, layers, c->n_rounds));
 }
 
 int qiddm_dense_sample_lean_prepare(const qiddm_circuit_t* c, const double* angles, const double* w_down,
@@ -103,14 +123,21 @@ int qiddm_dense_sample_lean_prepare(const qiddm_circuit_t* c, const double* angl
   if (features < 1 || features > 2048) return fail(QIDDM_ERR_INVALID, "features=%lld outside 1..2048", (long long)features);
   const qiddm::KScalars p = params_of(c);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (c->dtype == QIDDM_F32)
-    hipLaunchKernelGGL(qiddm::quad8_tables_kernel<float>, dim3(1), dim3(256), 0, st, angles, w_down, b_down, w_up, b_up,
-                       (int)features, static_cast<unsigned char*>(tables), p);
-  else
-    hipLaunchKernelGGL(qiddm::quad8_tables_kernel<double>, dim3(1), dim3(256), 0, st, angles, w_down, b_down, w_up, b_up,
-                       (int)features, static_cast<unsigned char*>(tables), p);
+  unsigned char* tb = static_cast<unsigned char*>(tables);
+  const int f = (int)features;
+  if (c->n_qubits == 8) {
+    if (c->dtype == QIDDM_F32)
+      hipLaunchKernelGGL((qiddm::lean_tables_kernel<float, 8>), dim3(1), dim3(256), 0, st, angles, w_down, b_down, w_up, b_up, f, tb, p);
+    else
+      hipLaunchKernelGGL((qiddm::lean_tables_kernel<double, 8>), dim3(1), dim3(256), 0, st, angles, w_down, b_down, w_up, b_up, f, tb, p);
+  } else {
+    if (c->dtype == QIDDM_F32)
+      hipLaunchKernelGGL((qiddm::lean_tables_kernel<float, 6>), dim3(1), dim3(256), 0, st, angles, w_down, b_down, w_up, b_up, f, tb, p);
+    else
+      hipLaunchKernelGGL((qiddm::lean_tables_kernel<double, 6>), dim3(1), dim3(256), 0, st, angles, w_down, b_down, w_up, b_up, f, tb, p);
+  }
   const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "quad8_tables_kernel launch failed: %s", hipGetErrorString(e));
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "lean_tables_kernel launch failed: %s", hipGetErrorString(e));
   return QIDDM_OK;
 }
 
@@ -123,7 +150,7 @@ int qiddm_dense_sample_lean_check(const qiddm_circuit_t* c, const void* tables, 
   hipError_t e = hipMemcpyAsync(&tmax, tables, sizeof(double), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
   if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "reading the tables' max |tan| failed: %s", hipGetErrorString(e));
-  return (tmax == tmax && tmax <= qiddm::kQuad8MaxTan) ? 1 : 0;
+  return (tmax == tmax && tmax <= qiddm::kLeanMaxTan) ? 1 : 0;
 }
 
 int qiddm_dense_sample_lean(const qiddm_circuit_t* c, const double* x, int64_t batch, int64_t x_ld, int64_t features,
@@ -155,8 +182,9 @@ int qiddm_dense_sample_lean(const qiddm_circuit_t* c, const double* x, int64_t b
   d.noise_factor = 1.0;
   d.stamps = qiddm_capi::stamp_buffer(8);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  return c->dtype == QIDDM_F32 ? dispatch_lean<float>(x, w_down, b_down, w_up, b_up, y, tables, d, p, layers, st)
-                               : dispatch_lean<double>(x, w_down, b_down, w_up, b_up, y, tables, d, p, layers, st);
+  return c->dtype == QIDDM_F32
+             ? dispatch_lean<float>(c->n_qubits, x, w_down, b_down, w_up, b_up, y, tables, d, p, layers, st)
+             : dispatch_lean<double>(c->n_qubits, x, w_down, b_down, w_up, b_up, y, tables, d, p, layers, st);
 }
 
 }  // extern "C"

@@ -1,7 +1,9 @@
-// qsim_quad8.h -- the sampling loop of the 8-qubit dense nets with the layer's dependent chain cut to the bone.
+// qsim_lean.h -- the sampling loop of the 8- and 6-qubit dense nets with the layer's dependent chain cut to the bone.
 //
-// Same decomposition as qsim_quad.h (four wavefronts per sample, amplitude k = (wave << 6) | lane, one LDS exchange per
-// layer for the two wave-bit gates), but built around what the microbenchmark of tools/ubench/ubench_quad.hip says a
+// Same decomposition as qsim_quad.h (8 qubits: four wavefronts per sample, amplitude k = (wave << 6) | lane, one LDS
+// exchange per layer for the two wave-bit gates; 6 qubits: the state fits one wavefront, every wave runs the circuit on
+// its own copy and there is no exchange and no barrier in a round), but built around what the microbenchmarks of
+// tools/ubench/ say a
 // LONE wavefront on a SIMD pays: ~11 cycles per DEPENDENT vector instruction whatever it is, ~155 cycles for the LDS
 // round trip + barrier.  A layer is a dependent chain (every gate acts on the same amplitudes), so its time is
 // (chain depth) x 11 + 155 and the only lever is depth:
@@ -18,33 +20,35 @@
 //     into one of two register sets that alternate (no copies).
 //   * linear_down is NOT evaluated per step: with goal = "data" the loop is x <- net(x) with no clamp (reference
 //     src/models.py:127-129), so the next step's angles are (W_down W_up) z + (W_down b_up + b_down) with z = <Z> of
-//     this step -- an 8 x 8 product built once per weights (quad8_tables_kernel).  Where the angles cannot reach the
+//     this step -- an n x n product built once per weights (lean_tables_kernel).  Where the angles cannot reach the
 //     state at all (one block per round: RZ on |0..0> is a global phase, finding F2) they are not computed.
 //
 // The tangent form needs cos(theta / 2) away from zero: the table builder records max |t|; the host routes weights with
-// max |t| > kQuad8MaxTan to dense_quad_kernel (qiddm_dense_sample_lean_check).  Shipped checkpoints have |theta / 2| < 0.9.
+// max |t| > kLeanMaxTan to dense_quad_kernel (qiddm_dense_sample_lean_check).  Shipped checkpoints have |theta / 2| < 0.9.
 #pragma once
 #include "qsim_quad.h"
 
 namespace qiddm {
 
-constexpr double kQuad8MaxTan = 16.0;
-constexpr int kQuad8HeaderDoubles = 80;   // [0] max |t|, [1..64] M = W_down W_up (row-major [j][i]), [65..72] v, pad
+constexpr double kLeanMaxTan = 16.0;
+constexpr int kLeanHeaderDoubles = 80;   // [0] max |t|, [1 .. n n] M = W_down W_up (row-major [j][i]), then v [n], pad
 
 // layout of the lean tables behind the header, in elements of T (built once per weights, copied to LDS per launch)
-template <typename T>
-struct Quad8Tables {
-  // per layer: ph[256] complex (thread order), un[8] = t of index bits 0..7
-  __host__ __device__ static constexpr size_t ph_elems(int layers) { return (size_t)layers * 256 * 2; }
+template <typename T, int N>
+struct LeanTables {
+  static_assert(N == 6 || N == 8, "lean sampling loop: 6 or 8 qubits");
+  static constexpr int TL = N == 8 ? 256 : 64;   // amplitudes = phase-table entries per layer (thread / lane order)
+  // per layer: ph[TL] complex, un[8] = tangent of index bits 0..N-1
+  __host__ __device__ static constexpr size_t ph_elems(int layers) { return (size_t)layers * TL * 2; }
   __host__ __device__ static constexpr size_t un_elems(int layers) { return (size_t)layers * 8; }
-  __host__ __device__ static constexpr size_t a0_elems(int rounds) { return (size_t)rounds * 256; }
+  __host__ __device__ static constexpr size_t a0_elems(int rounds) { return (size_t)rounds * TL; }
   __host__ __device__ static size_t elems(int layers, int rounds) {
     return ph_elems(layers) + un_elems(layers) + a0_elems(rounds);
   }
   __host__ __device__ static size_t bytes(int layers, int rounds) {
-    return (size_t)kQuad8HeaderDoubles * sizeof(double) + elems(layers, rounds) * sizeof(T);
+    return (size_t)kLeanHeaderDoubles * sizeof(double) + elems(layers, rounds) * sizeof(T);
   }
-  // LDS of dense_quad8_kernel: the tables, the double-buffered exchange slab, partial sums and per-wave angle copies
+  // LDS of dense_lean_kernel: the tables, the double-buffered exchange slab, partial sums and per-wave angle copies
   __host__ __device__ static size_t lds_bytes(int layers, int rounds) {
     return (elems(layers, rounds) * sizeof(T) + 15) / 16 * 16 + (size_t)2 * 4 * kWave * 2 * sizeof(T) +
            (size_t)(3 * 4 * 16 + 3 * 4 * 16 + 80) * sizeof(double);
@@ -52,41 +56,41 @@ struct Quad8Tables {
 };
 
 // ---- table builder: one 256-thread workgroup --------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void quad8_tables_kernel(const double* __restrict__ angles,
-                                                           const double* __restrict__ wd, const double* __restrict__ bd,
-                                                           const double* __restrict__ wu, const double* __restrict__ bu,
-                                                           int features, unsigned char* __restrict__ tables,
-                                                           const KScalars p) {
-  constexpr int N = 8;
+template <typename T, int N>
+__global__ __launch_bounds__(256) void lean_tables_kernel(const double* __restrict__ angles,
+                                                          const double* __restrict__ wd, const double* __restrict__ bd,
+                                                          const double* __restrict__ wu, const double* __restrict__ bu,
+                                                          int features, unsigned char* __restrict__ tables,
+                                                          const KScalars p) {
   using C = V2<T>;
+  using LT = LeanTables<T, N>;
   __shared__ double s_alpha[1024];   // phi^l_w + omega^{l-1}_w per (layer, wire): layers <= 128
   __shared__ double s_c[1024], s_s[1024];
   __shared__ double s_max[256];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int lpr = p.n_blocks * p.sel_layers, layers = p.n_rounds * lpr, n_rot = layers * N;
   double* head = reinterpret_cast<double*>(tables);
-  T* body = reinterpret_cast<T*>(tables + kQuad8HeaderDoubles * sizeof(double));
+  T* body = reinterpret_cast<T*>(tables + kLeanHeaderDoubles * sizeof(double));
   C* ph = reinterpret_cast<C*>(body);
-  T* un = body + Quad8Tables<T>::ph_elems(layers);
-  T* a0 = un + Quad8Tables<T>::un_elems(layers);
+  T* un = body + LT::ph_elems(layers);
+  T* a0 = un + LT::un_elems(layers);
   double tmax = 0.0;
   for (int g = tid; g < n_rot; g += 256) {
     double c, sn;
     sincos(0.5 * angles[g * 3 + 1], &sn, &c);
     s_c[g] = c;
     s_s[g] = sn;
-    const int li = (g / N) % lpr;
+    const int li = (g / N) % lpr, w = g % N;
     s_alpha[g] = angles[g * 3 + 0] + (li > 0 ? angles[(g - N) * 3 + 2] : 0.0);
+    T t = (T)0;
     if (li > 0) {                                   // a round's first layer is generated from (c, s), never divided
-      const double t = c != 0.0 ? fabs(sn / c) : 1e300;
-      tmax = fmax(tmax, t);
-      const int w = g % N;
-      un[(g / N) * 8 + (N - 1 - w)] = (T)(c != 0.0 ? sn / c : 0.0);     // t of index bit q = N-1-w
-    } else {
-      un[(g / N) * 8 + (N - 1 - (g % N))] = (T)0;
+      tmax = fmax(tmax, c != 0.0 ? fabs(sn / c) : 1e300);
+      t = (T)(c != 0.0 ? sn / c : 0.0);
     }
+    un[(g / N) * 8 + (N - 1 - w)] = t;              // tangent of index bit q = N-1-w
   }
+  if (N < 8)
+    for (int i = tid; i < layers * (8 - N); i += 256) un[(i / (8 - N)) * 8 + N + i % (8 - N)] = (T)0;
   s_max[tid] = tmax;
   __syncthreads();
   if (tid == 0) {
@@ -94,40 +98,45 @@ __global__ __launch_bounds__(256) void quad8_tables_kernel(const double* __restr
     for (int i = 0; i < 256; ++i) m = fmax(m, s_max[i]);
     head[0] = m;
   }
-  const uint32_t k = ((uint32_t)wv << 6) | (uint32_t)logical_lane(lane);   // this thread's amplitude index
-  for (int l = 0; l < layers; ++l) {
-    const int li = l % lpr;
-    if (li == 0) {
-      // the round's first layer acts on |0..0>: a real product state (its diagonal is a global phase)
-      double f = 1.0;
+  // this thread's amplitude index (8 qubits: one per thread; 6 qubits: the first wavefront writes, one per lane)
+  const uint32_t k = (N == 8 ? ((uint32_t)wv << 6) : 0u) | (uint32_t)logical_lane(lane);
+  const int slot = N == 8 ? tid : lane;
+  if (N == 8 || wv == 0) {
+    for (int l = 0; l < layers; ++l) {
+      const int li = l % lpr;
+      if (li == 0) {
+        // the round's first layer acts on |0..0>: a real product state (its diagonal is a global phase)
+        double f = 1.0;
 #pragma unroll
-      for (int q = 0; q < N; ++q) f *= ((k >> q) & 1u) ? s_s[l * N + (N - 1 - q)] : s_c[l * N + (N - 1 - q)];
-      a0[(l / lpr) * 256 + tid] = (T)f;
-      ph[l * 256 + tid] = C{(T)1, (T)0};
-      continue;
-    }
-    double ang = 0.0, scale = 1.0;
+        for (int q = 0; q < N; ++q) f *= ((k >> q) & 1u) ? s_s[l * N + (N - 1 - q)] : s_c[l * N + (N - 1 - q)];
+        a0[(l / lpr) * LT::TL + slot] = (T)f;
+        ph[l * LT::TL + slot] = C{(T)1, (T)0};
+        continue;
+      }
+      double ang = 0.0, scale = 1.0;
 #pragma unroll
-    for (int q = 0; q < N; ++q) {
-      const double al = s_alpha[l * N + (N - 1 - q)];
-      ang += ((k >> q) & 1u) ? 0.5 * al : -0.5 * al;
-      scale *= s_c[l * N + q];                       // every factor cos(theta_w / 2) of THIS layer's RYs
+      for (int q = 0; q < N; ++q) {
+        const double al = s_alpha[l * N + (N - 1 - q)];
+        ang += ((k >> q) & 1u) ? 0.5 * al : -0.5 * al;
+        scale *= s_c[l * N + q];                       // every factor cos(theta_w / 2) of THIS layer's RYs
+      }
+      double c, sn;
+      sincos(ang, &sn, &c);
+      if (cz_ring_parity<N>(k, ((li - 1) % p.sel_layers) % (N - 1) + 1)) scale = -scale;   // CZ ring of the layer before
+      ph[l * LT::TL + slot] = C{(T)(c * scale), (T)(sn * scale)};
     }
-    double c, sn;
-    sincos(ang, &sn, &c);
-    if (cz_ring_parity<N>(k, ((li - 1) % p.sel_layers) % (N - 1) + 1)) scale = -scale;   // CZ ring of the layer before
-    ph[l * 256 + tid] = C{(T)(c * scale), (T)(sn * scale)};
   }
   // M = W_down W_up and v = W_down b_up + b_down (float64): the angles of the NEXT step from this step's <Z>
-  if (wd != nullptr && wu != nullptr && tid < 72) {
-    const int j = tid < 64 ? tid / 8 : tid - 64, i = tid % 8;
+  if (wd != nullptr && wu != nullptr && tid < N * N + N) {
     double acc = 0.0;
-    if (tid < 64) {
+    if (tid < N * N) {
+      const int j = tid / N, i = tid % N;
       for (int px = 0; px < features; ++px) acc = fma(wd[(size_t)j * features + px], wu[(size_t)px * N + i], acc);
       head[1 + tid] = acc;
     } else {
+      const int j = tid - N * N;
       for (int px = 0; px < features; ++px) acc = fma(wd[(size_t)j * features + px], bu ? bu[px] : 0.0, acc);
-      head[65 + j] = acc + (bd ? bd[j] : 0.0);
+      head[1 + N * N + j] = acc + (bd ? bd[j] : 0.0);
     }
   }
 }
@@ -185,7 +194,7 @@ __device__ __forceinline__ void ry_t_swap(V2<T>& a, T t) {
 
 // what a thread holds for one layer
 template <typename T>
-struct Quad8Layer {
+struct LeanLayer {
   V2<T> ph;
   T ts[4];       // index bits 0..3, signed by this lane's bit
   T t4, t5;
@@ -196,14 +205,14 @@ struct Quad8Layer {
 //       angle code is compiled at all (no branch in the layer either: a taken branch costs a lone wavefront ~50 cycles).
 // LPR:  layers per round as a compile-time constant (fully unrolled layer sequence; 14 = the flagship QNN_noise(784, 8,
 //       14), 12 = the LL-style (6 blocks x 2)), or 0 for a runtime count (loop over pairs of layers).
-template <typename T, int PPT, bool REUP, int LPR>
-__global__ __launch_bounds__(256) void dense_quad8_kernel(
+template <typename T, int N, int PPT, bool REUP, int LPR>
+__global__ __launch_bounds__(256) void dense_lean_kernel(
     const double* __restrict__ x, const double* __restrict__ wd, const double* __restrict__ bd,
     const double* __restrict__ wu, const double* __restrict__ bu, double* __restrict__ y,
     const unsigned char* __restrict__ tables, const QuadScalars d, const KScalars p) {
-  constexpr int N = 8;
   using C = V2<T>;
-  using QT = Quad8Tables<T>;
+  using QT = LeanTables<T, N>;
+  constexpr int TL = QT::TL;
   using V4 = T __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int lpr = LPR > 0 ? LPR : p.n_blocks * p.sel_layers, layers = p.n_rounds * lpr;
@@ -235,7 +244,7 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
   }
   {
     // 16 bytes per thread and trip, four trips in flight (the element count is a multiple of four)
-    const V4* src = reinterpret_cast<const V4*>(tables + kQuad8HeaderDoubles * sizeof(double));
+    const V4* src = reinterpret_cast<const V4*>(tables + kLeanHeaderDoubles * sizeof(double));
     V4* dst = reinterpret_cast<V4*>(s_body);
     const int n4 = (int)(QT::elems(layers, p.n_rounds) / 4);
     int i = tid;
@@ -248,13 +257,14 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
     }
     for (; i < n4; i += 256) dst[i] = src[i];
   }
-  const uint32_t kbase = ((uint32_t)wv << 6) | (uint32_t)llane;
+  const uint32_t kbase = (N == 8 ? ((uint32_t)wv << 6) : 0u) | (uint32_t)llane;
+  const int slot = N == 8 ? tid : lane;   // this thread's entry of a per-amplitude table
   T pm[8];   // +-1 by this thread's index bit
 #pragma unroll
   for (int q = 0; q < 8; ++q) pm[q] = ((kbase >> q) & 1u) ? (T)1 : (T)-1;
   // composite map of the next step's angles (M row-major, then v) in LDS
   double* s_map = s_part_z + 5 * 4 * 16;   // [72]
-  if (REUP && tid < 72) s_map[tid] = head[1 + tid];
+  if (REUP && tid < N * N + N) s_map[tid] = head[1 + tid];
   auto wave_sync = [&]() {   // LDS hand-over inside the wavefront
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
     V4 lo, hi;   // t of index bits 0..3 / 4..7
   };
   auto fetch_layer = [&](Raw& r, int l) {
-    r.ph = s_ph[l * 256 + tid];
+    r.ph = s_ph[l * TL + slot];
     const V4* u = reinterpret_cast<const V4*>(s_un + l * 8);
     r.lo = u[0];
     r.hi = u[1];
@@ -279,9 +289,9 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
   if (stamp) d.stamps[1] = __builtin_amdgcn_s_memtime();
 
   int xbuf_parity = 0, zbuf_parity = 0;
-  double ev[N];   // <Z_w> of the last round: linear_up's input and the next step's composite input
+  double ev[8];   // <Z_w> of the last round (N used): linear_up's input and the next step's composite input
 #pragma unroll
-  for (int j = 0; j < N; ++j) ev[j] = 0.0;
+  for (int j = 0; j < 8; ++j) ev[j] = 0.0;
   for (int64_t sample = blockIdx.x; sample < p.batch; sample += gridDim.x) {
     for (int step = 0; step < d.n_steps; ++step) {
       const bool st = stamp && step == 1;
@@ -290,9 +300,9 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
       if constexpr (REUP) {
         if (step == 0) {
           // linear_down on the input image (the only step that reads an image)
-          double acc[N];
+          double acc[8];
 #pragma unroll
-          for (int j = 0; j < N; ++j) acc[j] = 0.0;
+          for (int j = 0; j < 8; ++j) acc[j] = 0.0;
 #pragma unroll 1
           for (int i = 0; i < PPT; ++i) {     // (pixel by pixel: once per launch and sample, keep its registers few)
             const int pix = tid + i * 256;
@@ -310,8 +320,8 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
         } else {
           // x <- net(x) without a clamp: linear_down(linear_up(z)) = M z + v, z = the last step's <Z> (in registers);
           // lane j < 8 takes row j (every lane computes a row -- j = lane & 7 -- so nothing branches), two chains of four
-          const double* mr = s_map + (lane & 7) * N;
-          double h0 = s_map[64 + (lane & 7)], h1 = 0.0;
+          const double* mr = s_map + (lane & 7) * N;   // (rows beyond N read the table's padding: never stored)
+          double h0 = s_map[N * N + (lane & 7)], h1 = 0.0;
 #pragma unroll
           for (int i = 0; i < N; i += 2) {
             h0 = fma(mr[i], ev[i], h0);
@@ -326,18 +336,18 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
         const int l0 = round * lpr;
         C dx{(T)1, (T)0};
         if constexpr (REUP) {
-          T* s_cst = reinterpret_cast<T*>(s_cs);   // [8] cos(x_w / 2), then [8] sin(x_w / 2): this wave's copy
+          T* s_cst = reinterpret_cast<T*>(s_cs);   // [8] cos(x_w / 2), then [8] sin(x_w / 2) (N used): this wave's copy
           if (lane < N) {
             if constexpr (sizeof(T) == 4) {
               float s, c;
               data_sincos_f32(0.5 * s_xs[lane], &s, &c);
               s_cst[lane] = c;
-              s_cst[N + lane] = s;
+              s_cst[8 + lane] = s;
             } else {
               double s, c;
               sincos(0.5 * s_xs[lane], &s, &c);
               s_cst[lane] = c;
-              s_cst[N + lane] = s;
+              s_cst[8 + lane] = s;
             }
           }
           wave_sync();
@@ -350,20 +360,27 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
           C z[8];
 #pragma unroll
           for (int q = 0; q < N; ++q) z[q] = C{cw[N - 1 - q], sw[N - 1 - q] * pm[q]};
+          if constexpr (N == 8) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) z[q] = cmul2<T>(z[q], z[q + 4], times_i<T>(z[q + 4]));
-          z[0] = cmul2<T>(z[0], z[2], times_i<T>(z[2]));
-          z[1] = cmul2<T>(z[1], z[3], times_i<T>(z[3]));
-          dx = cmul2<T>(z[0], z[1], times_i<T>(z[1]));
+            for (int q = 0; q < 4; ++q) z[q] = cmul2<T>(z[q], z[q + 4], times_i<T>(z[q + 4]));
+            z[0] = cmul2<T>(z[0], z[2], times_i<T>(z[2]));
+            z[1] = cmul2<T>(z[1], z[3], times_i<T>(z[3]));
+            dx = cmul2<T>(z[0], z[1], times_i<T>(z[1]));
+          } else {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) z[q] = cmul2<T>(z[q], z[q + 3], times_i<T>(z[q + 3]));
+            z[0] = cmul2<T>(z[0], z[1], times_i<T>(z[1]));
+            dx = cmul2<T>(z[0], z[2], times_i<T>(z[2]));
+          }
         }
         if (st && round == 0) d.stamps[7] = __builtin_amdgcn_s_memtime();
-        C a{s_a0[round * 256 + tid], (T)0};   // the round's first layer, generated
-        Quad8Layer<T> ca, cb;
+        C a{s_a0[round * TL + slot], (T)0};   // the round's first layer, generated
+        LeanLayer<T> ca, cb;
         Raw raw;
         int next_upload = REUP ? p.sel_layers : 0x7fffffff;   // first layer of block 1
         // what layer li will multiply the state by: its phase entry, times the data diagonal at a block start (selected,
         // not branched on: the product rides in empty issue slots a layer ahead)
-        auto derive_layer = [&](Quad8Layer<T>& c, const Raw& r, int li) {
+        auto derive_layer = [&](LeanLayer<T>& c, const Raw& r, int li) {
           c.ph = r.ph;
           if constexpr (REUP) {
             const bool up = li == next_upload;
@@ -377,15 +394,17 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
           c.ts[3] = r.lo.w * pm[3];
           c.t4 = r.hi.x;
           c.t5 = r.hi.y;
-          c.k1 = r.hi.z * pm[6];
-          c.k2 = r.hi.w * pm[7];
-          c.k3 = c.k1 * c.k2;
+          if constexpr (N == 8) {
+            c.k1 = r.hi.z * pm[6];
+            c.k2 = r.hi.w * pm[7];
+            c.k3 = c.k1 * c.k2;
+          }
         };
         if (lpr > 1) {
           fetch_layer(raw, l0 + 1);
           derive_layer(ca, raw, 1);
         }
-        auto layer = [&](const Quad8Layer<T>& cur, Quad8Layer<T>& nxt, int li) {
+        auto layer = [&](const LeanLayer<T>& cur, LeanLayer<T>& nxt, int li) {
           // the next layer's phase and tangents first: they land while this layer's chain runs, and what is derived from
           // them fills issue slots the chain leaves empty -- nothing table-related is left behind the barrier
           // (unconditional -- the last layer re-reads its own entry -- so that the wait counters are exact on every path)
@@ -396,16 +415,18 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
           ry_t_swap<5, T>(a, cur.t5);
           derive_layer(nxt, raw, li + 1);   // (the reads were issued ~100 cycles ago)
           ry_t_swap<4, T>(a, cur.t4);
-          C* buf = s_slab + (size_t)xbuf_parity * (4 * kWave);
-          xbuf_parity ^= 1;
-          buf[wv * kWave + lane] = a;
-          __syncthreads();
-          const C p1 = buf[(wv ^ 1) * kWave + lane];
-          const C p2 = buf[(wv ^ 2) * kWave + lane];
-          const C p3 = buf[(wv ^ 3) * kWave + lane];
-          const C o = __builtin_elementwise_fma(bcast<T>(cur.k1), p1, a);
-          const C t = __builtin_elementwise_fma(bcast<T>(cur.k3), p3, bcast<T>(cur.k2) * p2);
-          a = o + t;
+          if constexpr (N == 8) {   // the two wave bits: one real 4 x 4 through LDS
+            C* buf = s_slab + (size_t)xbuf_parity * (4 * kWave);
+            xbuf_parity ^= 1;
+            buf[wv * kWave + lane] = a;
+            __syncthreads();
+            const C p1 = buf[(wv ^ 1) * kWave + lane];
+            const C p2 = buf[(wv ^ 2) * kWave + lane];
+            const C p3 = buf[(wv ^ 3) * kWave + lane];
+            const C o = __builtin_elementwise_fma(bcast<T>(cur.k1), p1, a);
+            const C t = __builtin_elementwise_fma(bcast<T>(cur.k3), p3, bcast<T>(cur.k2) * p2);
+            a = o + t;
+          }
         };
         if constexpr (LPR > 0) {
 #pragma unroll
@@ -427,20 +448,32 @@ __global__ __launch_bounds__(256) void dense_quad8_kernel(
         const T pr = a.x * a.x + a.y * a.y;
         T ez[8];
 #pragma unroll
-        for (int w = 0; w < N; ++w) ez[w] = ((kbase >> (N - 1 - w)) & 1u) ? -pr : pr;
+        for (int w = 0; w < 8; ++w) ez[w] = (w < N && ((kbase >> (N - 1 - w)) & 1u)) ? -pr : (w < N ? pr : (T)0);
         // (two partial buffers in turn: a round without simulated layers has no barrier between one read-out's readers and
         //  the next one's writers)
         T* s_pz = reinterpret_cast<T*>(s_part_z + zbuf_parity * 4 * 16);
         zbuf_parity ^= 1;
         wave_reduce8_into<T, true>(ez, lane, llane, s_pz + wv * 16);
-        __syncthreads();
-        // every thread adds the four waves' partials itself (eight broadcast reads, no second LDS round trip), pairwise,
-        // in the engine's precision; float64 from there on
-        {
+        if constexpr (N == 8) {
+          __syncthreads();
+          // every thread adds the four waves' partials itself (eight broadcast reads, no second LDS round trip), pairwise,
+          // in the engine's precision; float64 from there on
           const V4* pz = reinterpret_cast<const V4*>(s_pz);
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const V4 q = (pz[h] + pz[4 + h]) + (pz[8 + h] + pz[12 + h]);
+            ev[4 * h + 0] = (double)q.x;
+            ev[4 * h + 1] = (double)q.y;
+            ev[4 * h + 2] = (double)q.z;
+            ev[4 * h + 3] = (double)q.w;
+          }
+        } else {
+          // every wave summed its own copy of the whole state: its own eight slots, no barrier
+          wave_sync();
+          const V4* pz = reinterpret_cast<const V4*>(s_pz + wv * 16);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const V4 q = pz[h];
             ev[4 * h + 0] = (double)q.x;
             ev[4 * h + 1] = (double)q.y;
             ev[4 * h + 2] = (double)q.z;

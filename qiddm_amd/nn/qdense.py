@@ -85,7 +85,7 @@ class _QuantumNet(nn.Module):
         return cached[1]
 
     def _lean_sampler_tables(self, circ, angles, lin_down, lin_up):
-        """Tables of the lean 8-qubit sampler (goal "data"), rebuilt only when the weights, the two linears or the
+        """Tables of the lean 8- / 6-qubit sampler (goal "data"), rebuilt only when the weights, the two linears or the
         precision changed; None when that kernel does not apply (then the general sampler runs)."""
         tensors = (angles, lin_down.weight, lin_down.bias, lin_up.weight, lin_up.bias)
         stamp = tuple((t._version, t.data_ptr()) for t in tensors if t is not None) + \
@@ -100,7 +100,7 @@ class _QuantumNet(nn.Module):
         return cached[1]
 
     def _fused_sampler_launch(self, circ, flat, angles, n_steps, goal, noise_factor):
-        """n_steps loop bodies in one launch: the lean 8-qubit kernel where it applies (goal "data"), else the general
+        """n_steps loop bodies in one launch: the lean 8- / 6-qubit kernel where it applies (goal "data"), else the general
         four-wavefront sampler."""
         ld, lu = self.linear_down, self.linear_up
         if goal == "data":

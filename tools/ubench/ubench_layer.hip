@@ -1,8 +1,8 @@
-// ubench_layer.hip -- the layer of dense_quad8_kernel (qsim_quad8.h) taken apart: the same instruction sequence with
+// ubench_layer.hip -- the layer of dense_quad8_kernel (qsim_lean.h) taken apart: the same instruction sequence with
 // one ingredient removed or changed per variant, 13 layers per "step", s_memtime around `iters` steps, one 256-thread
 // workgroup per CU on all 256 CUs.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -I../../qiddm_amd/csrc -o ubench_layer ubench_layer.hip && ./ubench_layer
-#include "qsim_quad8.h"
+#include "qsim_lean.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -60,20 +60,20 @@ __global__ __launch_bounds__(256) void layer_loop(float* out, unsigned long long
     r.lo = u[0];
     r.hi = u[1];
   };
-  auto derive = [&](Quad8Layer<T>& c, const Raw& r) {
+  auto derive = [&](LeanLayer<T>& c, const Raw& r) {
     c.ph = r.ph;
     c.ts[0] = r.lo.x * pm[0]; c.ts[1] = r.lo.y * pm[1]; c.ts[2] = r.lo.z * pm[2]; c.ts[3] = r.lo.w * pm[3];
     c.t4 = r.hi.x; c.t5 = r.hi.y;
     c.k1 = r.hi.z * pm[6]; c.k2 = r.hi.w * pm[7]; c.k3 = c.k1 * c.k2;
   };
-  Quad8Layer<T> ca, cb;
+  LeanLayer<T> ca, cb;
   Raw raw;
   fetch(raw, 0);
   derive(ca, raw);
   cb = ca;
   __syncthreads();
   int next_upload = next_upload_arg;
-  auto layer = [&](const Quad8Layer<T>& cur, Quad8Layer<T>& nxt, int li) {
+  auto layer = [&](const LeanLayer<T>& cur, LeanLayer<T>& nxt, int li) {
     constexpr bool tables = VAR == kFull || VAR == kFetchAfterBarrier || VAR >= kRuntimeLoop;
     constexpr bool full = VAR == kFull || VAR >= kRuntimeLoop;
     if constexpr (full) {
@@ -90,10 +90,7 @@ __global__ __launch_bounds__(256) void layer_loop(float* out, unsigned long long
     }
     if constexpr (VAR != kNoPhase && VAR != kOnlyExchange) a = cmul2<T>(phv, a, times_i<T>(a));
     if constexpr (VAR != kNoDpp && VAR != kOnlyExchange) {
-      ry_t_dpp<0xB1>(a, cur.ts[0]);
-      ry_t_dpp<0x4E>(a, cur.ts[1]);
-      ry_t_dpp<0x141>(a, cur.ts[2]);
-      ry_t_dpp<0x128>(a, cur.ts[3]);
+      ry_t_dpp4(a, cur.ts[0], cur.ts[1], cur.ts[2], cur.ts[3]);
     }
     if constexpr (VAR != kNoSwaps && VAR != kOnlyExchange) ry_t_swap<5, T>(a, cur.t5);
     if constexpr (full) derive(nxt, raw);
