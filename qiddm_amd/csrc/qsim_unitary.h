@@ -400,10 +400,19 @@ __global__ __launch_bounds__(4 * kWave, UP ? 1 : 2) void qconv_gemm_wide_kernel(
   float n2 = 0.f;
   __syncthreads();
 
-  double pv[KT];
-  uint32_t in_mask = 0;   // bit u: tap u of the chunk in flight lies inside the image
-  float bv[(kWideK * NBW) / (4 * kWave)];
-  auto fetch = [&](int k0) {
+  // The gather of an A chunk (strided float64 loads) is what the matrix cores used to wait for: with one chunk of
+  // distance the loads of chunk c + 1 had ONE MFMA phase (~1.7 us) to land, and under the load of 512 workgroups they did
+  // not (63 % of wave cycles waiting, matrix cores 58 % busy).  Now two register sets alternate: chunk c + 2 is requested
+  // before the MFMAs of chunk c (two phases of flight).  B (L2-resident, contiguous rows) keeps one chunk of distance
+  // but moves as 16-byte pieces -- 4 loads + 4 LDS stores per thread and chunk instead of 16 + 16 -- and is requested
+  // BEFORE the far gather, so that waiting for it (the load counter retires in order) leaves the gather in flight.
+  // (B by LDS-DMA was tried: the wait-count pass then drains vmcnt to zero in front of every LDS read behind a DMA.)
+  using F4 = float __attribute__((ext_vector_type(4)));
+  constexpr int kBV = (kWideK * NBW) / (4 * kWave) / 4;   // float4 pieces of B per thread and chunk
+  double pv0[KT], pv1[KT];
+  uint32_t mask0 = 0, mask1 = 0;   // bit u: tap u of that chunk lies inside the image
+  F4 bv[kBV];
+  auto fetch = [&](int k0, double (&pv)[KT], uint32_t& in_mask) {
     uint32_t tap[KT];
     in_mask = 0;
 #pragma unroll
@@ -425,15 +434,18 @@ __global__ __launch_bounds__(4 * kWave, UP ? 1 : 2) void qconv_gemm_wide_kernel(
         in_mask |= (uint32_t)in << u;
       }
     }
-#pragma unroll
-    for (int i = 0; i < (kWideK * NBW) / (4 * kWave); ++i) {
-      const int e = tid + i * 4 * kWave;
-      bv[i] = w[(size_t)(k0 + e / NBW) * g.N_pad + ct0 * 64 + (e % NBW)];
-    }
   };
-  auto stage = [&](int k0, int buf) {
+  // B chunk k0: wave w takes rows w, w + 4, ... -- one whole 1 KB row per wave instruction
+  auto fetch_b = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < kBV; ++i)
+      bv[i] = *reinterpret_cast<const F4*>(w + (size_t)(k0 + wave + 4 * i) * g.N_pad + ct0 * 64 + lane * 4);
+  };
+  auto stage = [&](int k0, int buf, const double (&pv)[KT], uint32_t in_mask) {
     float (*s_a)[kGemmM] = reinterpret_cast<float (*)[kGemmM]>(s_raw + buf * kStageBytes);
     float (*s_b)[NBW] = reinterpret_cast<float (*)[NBW]>(s_raw + buf * kStageBytes + kWideK * kGemmM * 4);
+#pragma unroll
+    for (int i = 0; i < kBV; ++i) *reinterpret_cast<F4*>(&s_b[wave + 4 * i][lane * 4]) = bv[i];
 #pragma unroll
     for (int u = 0; u < KT; ++u) {
       const int f = k0 + kh_s + u;
@@ -443,11 +455,6 @@ __global__ __launch_bounds__(4 * kWave, UP ? 1 : 2) void qconv_gemm_wide_kernel(
         n2 = fmaf(v, v, n2);
       }
       s_a[kh_s + u][m_s] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < (kWideK * NBW) / (4 * kWave); ++i) {
-      const int e = tid + i * 4 * kWave;
-      s_b[e / NBW][e % NBW] = bv[i];
     }
   };
 
@@ -459,13 +466,16 @@ __global__ __launch_bounds__(4 * kWave, UP ? 1 : 2) void qconv_gemm_wide_kernel(
       acc_re[sub][i] = 0.f;
       acc_im[sub][i] = 0.f;
     }
-  fetch(0);
-  stage(0, 0);
-  __syncthreads();
   int cur = 0;
-  for (int k0 = 0; k0 < g.K_pad; k0 += kWideK) {
+  // one K chunk: request B of chunk c + 1 and A of chunk c + 2, run the MFMAs of chunk c, stage chunk c + 1
+  auto chunk = [&](int k0, double (&pv_next)[KT], uint32_t& mask_next, double (&pv_far)[KT], uint32_t& mask_far) {
     const bool more = k0 + kWideK < g.K_pad;
-    if (more) fetch(k0 + kWideK);
+    const int k_last = g.K_pad - kWideK;
+    // (both requests unconditional -- past the end they repeat the last chunk and are never staged -- so that the wait
+    //  counters behind them are exact on every path: a conditional request makes the pass assume the shorter queue)
+    fetch_b(k0 + kWideK < k_last ? k0 + kWideK : k_last);
+    __builtin_amdgcn_sched_barrier(0);   // B's loads are issued first: "B has landed" must not imply "the far gather has"
+    fetch(k0 + 2 * kWideK < k_last ? k0 + 2 * kWideK : k_last, pv_far, mask_far);
     const float (*s_a)[kGemmM] = reinterpret_cast<const float (*)[kGemmM]>(s_raw + cur * kStageBytes);
     const float (*s_b)[NBW] = reinterpret_cast<const float (*)[NBW]>(s_raw + cur * kStageBytes + kWideK * kGemmM * 4);
     // operands of k-step i + 1 are read from LDS while the eight MFMAs of step i issue (two register sets): as one
@@ -492,10 +502,21 @@ __global__ __launch_bounds__(4 * kWave, UP ? 1 : 2) void qconv_gemm_wide_kernel(
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the reads of step i + 1 in front of the MFMAs of step i
     }
-    if (more) stage(k0 + kWideK, cur ^ 1);
+    if (more) stage(k0 + kWideK, cur ^ 1, pv_next, mask_next);
     __syncthreads();
     cur ^= 1;
+  };
+  fetch_b(0);
+  fetch(0, pv0, mask0);
+  fetch(kWideK < g.K_pad ? kWideK : 0, pv1, mask1);
+  stage(0, 0, pv0, mask0);
+  __syncthreads();
+  int kc = 0;
+  for (; kc + kWideK < g.K_pad; kc += 2 * kWideK) {
+    chunk(kc, pv1, mask1, pv0, mask0);            // chunk c even: c + 1 waits in set 1, c + 2 goes to set 0
+    chunk(kc + kWideK, pv0, mask0, pv1, mask1);
   }
+  if (kc < g.K_pad) chunk(kc, pv1, mask1, pv0, mask0);
   s_n2[tid >> 7][m_s] = n2;
   __syncthreads();
   if (tid < kGemmM) s_inv[tid] = (float)(g.post_scale / ((double)s_n2[0][tid] + (double)s_n2[1][tid] + g.pad_norm2));
