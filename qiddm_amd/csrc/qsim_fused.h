@@ -422,6 +422,45 @@ struct Engine {
   __device__ __forceinline__ void fill_folded_from_table(const T* __restrict__ tail, int n_layers_all) {
     for (int i = threadIdx.x; i < n_layers_all * S::kFoldStride; i += blockDim.x) s_gates_w[i] = tail[i];
   }
+  // Tangent form for forward-only kernels (round 3; see qsim_lean.h): RY = c [[1, -t], [t, 1]] makes a gate ONE
+  // multiply-add per amplitude component (fused with the DPP fetch where the partner is a lane) instead of multiply +
+  // multiply-add, and the factors c of a layer commute with everything.  Done in place on the staged tables, after
+  // fill_folded_*(): for every layer that is SIMULATED (li > 0: a round's first layer stays (cos, sin) for the product
+  // state) ry[w] = (cos, sin) becomes (tan, cos) and the lane-part phases t_lo are multiplied by prod_w cos_w.  Returns
+  // false -- tables untouched -- when some |tan| exceeds 16 (cos(theta/2) within 3.6 degrees of zero): the caller then
+  // runs the (cos, sin) path.  Every thread of the block calls it; it ends with a barrier.
+  __device__ __forceinline__ bool tangent_fold(int n_layers_all, int layers_per_round) {
+    bool bad = false;
+    for (int i = threadIdx.x; i < n_layers_all * N; i += blockDim.x) {
+      const int l = i / N, w = i - l * N;
+      if (l % layers_per_round == 0) continue;
+      const T* e = s_gates_w + (size_t)l * S::kFoldStride + 2 * w;
+      const T c = e[0], sn = e[1];
+      bad |= !(fabs(sn) <= (T)16 * fabs(c));
+    }
+    if (__syncthreads_or(bad)) return false;
+    for (int i = threadIdx.x; i < n_layers_all * LPS; i += blockDim.x) {
+      const int l = i / LPS, k = i - l * LPS;
+      if (l % layers_per_round == 0) continue;
+      T* base = s_gates_w + (size_t)l * S::kFoldStride;
+      T scale = 1;
+#pragma unroll
+      for (int w = 0; w < N; ++w) scale *= base[2 * w];
+      base[2 * (N + k)] *= scale;
+      base[2 * (N + k) + 1] *= scale;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_layers_all * N; i += blockDim.x) {
+      const int l = i / N, w = i - l * N;
+      if (l % layers_per_round == 0) continue;
+      T* e = s_gates_w + (size_t)l * S::kFoldStride + 2 * w;
+      const T c = e[0], sn = e[1];
+      e[0] = sn / c;
+      e[1] = c;
+    }
+    __syncthreads();
+    return true;
+  }
   struct FoldedLayer {
     C ry[N];
     C tlo;
@@ -550,6 +589,97 @@ struct Engine {
                               __builtin_amdgcn_readfirstlane(__double2loint(v)));
     }
   }
+  // own += ts * partner for every amplitude of the lane, partner across lane bit Q < 4 (one DPP move inside the
+  // multiply-add; see qsim_lean.h for the wait states -- here the R >= 1 pairs of a gate sit between the write and the
+  // next gate's read of a register, one `s_nop 1` in front of each block covers the code before it)
+  template <int CTRL, int CNT>
+  __device__ __forceinline__ static void dpp_fmac_block(C* a, float ts) {
+    static_assert(CNT == 1 || CNT == 2 || CNT == 4 || CNT == 8, "amplitudes per asm block");
+#define QIDDM_DPP_FMAC(CTRLSTR)                                                                                        \
+    if constexpr (CNT == 1) {                                                                                          \
+      asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %2 " CTRLSTR "\n\tv_fmac_f32_dpp %1, %1, %2 " CTRLSTR "\n\ts_nop 0"   \
+                   : "+v"(a[0].x), "+v"(a[0].y) : "v"(ts));                                                            \
+    } else if constexpr (CNT == 2) {                                                                                   \
+      asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %4 " CTRLSTR "\n\tv_fmac_f32_dpp %1, %1, %4 " CTRLSTR                \
+                   "\n\tv_fmac_f32_dpp %2, %2, %4 " CTRLSTR "\n\tv_fmac_f32_dpp %3, %3, %4 " CTRLSTR                        \
+                   : "+v"(a[0].x), "+v"(a[0].y), "+v"(a[1].x), "+v"(a[1].y) : "v"(ts));                                \
+    } else if constexpr (CNT == 4) {                                                                                   \
+      asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %8 " CTRLSTR "\n\tv_fmac_f32_dpp %1, %1, %8 " CTRLSTR                \
+                   "\n\tv_fmac_f32_dpp %2, %2, %8 " CTRLSTR "\n\tv_fmac_f32_dpp %3, %3, %8 " CTRLSTR                        \
+                   "\n\tv_fmac_f32_dpp %4, %4, %8 " CTRLSTR "\n\tv_fmac_f32_dpp %5, %5, %8 " CTRLSTR                        \
+                   "\n\tv_fmac_f32_dpp %6, %6, %8 " CTRLSTR "\n\tv_fmac_f32_dpp %7, %7, %8 " CTRLSTR                        \
+                   : "+v"(a[0].x), "+v"(a[0].y), "+v"(a[1].x), "+v"(a[1].y), "+v"(a[2].x), "+v"(a[2].y), "+v"(a[3].x), \
+                     "+v"(a[3].y) : "v"(ts));                                                                          \
+    } else {                                                                                                           \
+      asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %0, %16 " CTRLSTR "\n\tv_fmac_f32_dpp %1, %1, %16 " CTRLSTR              \
+                   "\n\tv_fmac_f32_dpp %2, %2, %16 " CTRLSTR "\n\tv_fmac_f32_dpp %3, %3, %16 " CTRLSTR                      \
+                   "\n\tv_fmac_f32_dpp %4, %4, %16 " CTRLSTR "\n\tv_fmac_f32_dpp %5, %5, %16 " CTRLSTR                      \
+                   "\n\tv_fmac_f32_dpp %6, %6, %16 " CTRLSTR "\n\tv_fmac_f32_dpp %7, %7, %16 " CTRLSTR                      \
+                   "\n\tv_fmac_f32_dpp %8, %8, %16 " CTRLSTR "\n\tv_fmac_f32_dpp %9, %9, %16 " CTRLSTR                      \
+                   "\n\tv_fmac_f32_dpp %10, %10, %16 " CTRLSTR "\n\tv_fmac_f32_dpp %11, %11, %16 " CTRLSTR                  \
+                   "\n\tv_fmac_f32_dpp %12, %12, %16 " CTRLSTR "\n\tv_fmac_f32_dpp %13, %13, %16 " CTRLSTR                  \
+                   "\n\tv_fmac_f32_dpp %14, %14, %16 " CTRLSTR "\n\tv_fmac_f32_dpp %15, %15, %16 " CTRLSTR                  \
+                   : "+v"(a[0].x), "+v"(a[0].y), "+v"(a[1].x), "+v"(a[1].y), "+v"(a[2].x), "+v"(a[2].y), "+v"(a[3].x), \
+                     "+v"(a[3].y), "+v"(a[4].x), "+v"(a[4].y), "+v"(a[5].x), "+v"(a[5].y), "+v"(a[6].x), "+v"(a[6].y), \
+                     "+v"(a[7].x), "+v"(a[7].y) : "v"(ts));                                                            \
+    }
+    if constexpr (CTRL == 0xB1) {
+      QIDDM_DPP_FMAC("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+    } else if constexpr (CTRL == 0x4E) {
+      QIDDM_DPP_FMAC("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1")
+    } else if constexpr (CTRL == 0x141) {
+      QIDDM_DPP_FMAC("row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1")
+    } else {
+      static_assert(CTRL == 0x128, "lane bits 0..3");
+      QIDDM_DPP_FMAC("row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
+    }
+#undef QIDDM_DPP_FMAC
+  }
+  template <int Q>
+  __device__ __forceinline__ void ry_lane_tan(C (&a)[R], T t) const {
+    static_assert(Q >= 0 && Q < 4, "DPP lane bits");
+    const T ts = ((llane >> Q) & 1) ? t : -t;
+    if constexpr (sizeof(T) == 4) {
+      constexpr int CTRL = Q == 0 ? 0xB1 : Q == 1 ? 0x4E : Q == 2 ? 0x141 : 0x128;
+      constexpr int CNT = R >= 8 ? 8 : R;
+#pragma unroll
+      for (int r0 = 0; r0 < R; r0 += CNT) dpp_fmac_block<CTRL, CNT>(&a[r0], ts);
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const C par = xlane2<(1 << Q), T>(a[r], lane);
+        a[r] = __builtin_elementwise_fma(bcast<T>(ts), par, a[r]);
+      }
+    }
+  }
+  template <int J>
+  __device__ __forceinline__ static void ry_pairs_tan(C (&a)[R], T t) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if ((r & J) == 0) {
+        const C a0 = a[r], a1 = a[r | J];
+        a[r] = __builtin_elementwise_fma(bcast<T>(-t), a1, a0);
+        a[r | J] = __builtin_elementwise_fma(bcast<T>(t), a0, a1);
+      }
+    }
+  }
+  template <int W>
+  __device__ __forceinline__ void ry_wires_u_tan(C (&a)[R], const C* __restrict__ base) const {
+    if constexpr (W < N) {
+      constexpr int Q = N - 1 - W;
+      const T t = uni(base[W].x);
+      if constexpr (kind_of<W>() == kReg) {
+        ry_pairs_tan<(1 << (Q >= LB ? Q - LB : 0))>(a, t);
+      } else if constexpr (kind_of<W>() == kSwap) {
+        swap_reg0_with_lane_bit<Q>(a);
+        ry_pairs_tan<1>(a, t);
+        swap_reg0_with_lane_bit<Q>(a);
+      } else {
+        ry_lane_tan<Q>(a, t);
+      }
+      ry_wires_u_tan<W + 1>(a, base);
+    }
+  }
   template <int W>
   __device__ __forceinline__ void ry_wires_u(C (&a)[R], const C* __restrict__ base) const {
     if constexpr (W < N) {
@@ -573,6 +703,7 @@ struct Engine {
       ry_wires_u<W + 1>(a, base);
     }
   }
+  template <bool TAN = false>
   __device__ __forceinline__ void folded_round_u(const KScalars& p, C (&a)[R], const C (&dx)[R], int first_layer) const {
     const int layers = p.n_blocks * p.sel_layers;
     int li0 = 0;
@@ -604,7 +735,8 @@ struct Engine {
         const uint32_t sb = ((cz >> r) & 1u) << 31;
         a[r] = C{flip_sign(v.x, sb), flip_sign(v.y, sb)};
       }
-      ry_wires_u<0>(a, base);
+      if constexpr (TAN) ry_wires_u_tan<0>(a, base);
+      else ry_wires_u<0>(a, base);
     }
   }
 
@@ -944,6 +1076,7 @@ struct Engine {
   // -- the same for CZ circuits with no / RZ encoding on the folded tables ONLY: nothing of the general gate path, the
   //    CNOT scatter or the amplitude embedding is compiled in, which is what lets the n = 9 / 10 forward fit two
   //    waves per SIMD (circuit_folded_kernel) ---------------------------------------------------------------------
+  template <bool TAN = false>
   __device__ __forceinline__ void run_folded(const KScalars& p, T (&xs)[N], T (&result)[N], T (&pr)[R]) const {
     C a[R];
     C dx[R];
@@ -956,7 +1089,7 @@ struct Engine {
         half_angle_sincos(xs, cs, sn);
         rz_diagonal(cs, sn, dx);
       }
-      folded_round_u(p, a, dx, round * p.n_blocks * p.sel_layers);
+      folded_round_u<TAN>(p, a, dx, round * p.n_blocks * p.sel_layers);
 #pragma unroll
       for (int r = 0; r < R; ++r) pr[r] = a[r].x * a[r].x + a[r].y * a[r].y;
       if (p.measure == 1) {
@@ -1119,6 +1252,8 @@ __global__ __launch_bounds__(4 * kWave, (sizeof(T) == 4 ? 2 : 1)) void circuit_f
   eng.fill_folded_from_table(table + (size_t)n_rot * kVariants * kGateReals, n_rot / N);
   eng.fill_rings(false);
   __syncthreads();
+  // tangent-form layers where the weights allow it (a launch-uniform choice; round 3)
+  const bool tan_ok = eng.tangent_fold(n_rot / N, p.n_blocks * p.sel_layers);
   const int sub = eng.sub;
   const int wave = threadIdx.x >> 6;
   const int swave = eng.llane >> LB;
@@ -1138,7 +1273,8 @@ __global__ __launch_bounds__(4 * kWave, (sizeof(T) == 4 ? 2 : 1)) void circuit_f
       for (int j = 0; j < N; ++j) xs[j] = (T)0;
     }
     T result[N], pr[R];
-    eng.run_folded(p, xs, result, pr);
+    if (tan_ok) eng.template run_folded<true>(p, xs, result, pr);
+    else eng.template run_folded<false>(p, xs, result, pr);
     if (p.measure == 0) {
       if (valid) {
 #pragma unroll
