@@ -143,7 +143,13 @@ int launch(const Ptrs& ptr, const qiddm::KScalars& p, int64_t n_replicas, hipStr
     static const bool all_paths = std::getenv("QIDDM_NO_LEAN") != nullptr;   // kernel experiments: A/B
     // ... when there is more than one wave of work per SIMD: below that the all-paths kernel's one-layer-ahead table
     // prefetch wins (n = 10, 256 samples: 69.8 vs 76.5 us; 4096: 274 vs 245; 65 536: 4.18 vs 3.68 ms, gpurun_out/r02g)
-    if (p.fold && p.encoding != QIDDM_ENC_AMPLITUDE && !all_paths && groups > 1024) {
+    // Round 3: the lean kernel runs its layers in tangent form (Engine::tangent_fold; n = 8, 65 536 samples, G = 232 / 480:
+    // 0.40 / 0.66 -> 0.30 / 0.51 ms; n = 10, G = 900, 4096 samples: 245 -> 189 us).  At one wave per SIMD the all-paths
+    // kernel still wins at n = 8, 9 (B = 1024: 12.0 vs 14.7, 27.7 vs 31.8 us); at n = 10 the lean kernel wins at every
+    // batch (B = 1024: 64.9 vs 69.5 us; tools/ab_lean_threshold.py, gpurun_out/ab_lean_*.log).  QIDDM_LEAN_ABOVE: A/B.
+    static const int64_t lean_above_env = std::getenv("QIDDM_LEAN_ABOVE") ? std::atoll(std::getenv("QIDDM_LEAN_ABOVE")) : -1;
+    const int64_t lean_above = lean_above_env >= 0 ? lean_above_env : (N == 10 ? 0 : 1024);
+    if (p.fold && p.encoding != QIDDM_ENC_AMPLITUDE && !all_paths && groups > lean_above) {
       auto kf = qiddm::circuit_folded_kernel<T, N>;
       static qiddm_capi::DeviceFlags big_lds_folded;
       if (smem > 48 * 1024 && !big_lds_folded.get()) {
