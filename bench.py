@@ -101,7 +101,7 @@ VALU_PEAK_TF = 157.3           # f32 vector peak (= the f32 MFMA peak), same gui
 N_QUBITS, QDEPTH, IMG = 8, 14, 28
 MIN_TIMED_S = 0.05
 HEADLINE_KERNEL = "qiddm::dense_lean_kernel<{}, 8, 4, false, 14>"
-TRAFFIC_PROFILE = "profiles/r02c/bench_pmc_traffic.json"     # FETCH_SIZE / WRITE_SIZE passes of the driver's command
+TRAFFIC_PROFILE = "profiles/r03a/bench_pmc_traffic.json"     # FETCH_SIZE / WRITE_SIZE passes of the driver's command
 HEADLINE_NOTE = ("latency-bound at batch 256: one sample per CU, one wavefront per SIMD, and a layer is ONE dependent chain "
                  "(every gate acts on the same 256 amplitudes): ~11 cycles per dependent vector instruction for a lone "
                  "wavefront + ~230 for the LDS exchange of the two wave-bit gates (tools/ubench/). All 14 layers of every "
@@ -810,7 +810,8 @@ def main(argv=None):
         flop = lean_flop(N_QUBITS, QDEPTH, 1, IMG * IMG, False)   # what the kernel executes (tangent-form layers)
         std_flop = dense_flop(N_QUBITS, QDEPTH, 1, IMG * IMG)     # the same circuit in the (c, s) form of round 2
         valu_tf = flop * args.batch * kspl / (kern_us * 1e-6) / 1e12
-        io_bytes = (kspl + 1) * args.batch * IMG * IMG * 8        # first image in + one image out per step (exact)
+        io_bytes = kspl * args.batch * IMG * IMG * 8              # one image out per step (exact); the input image is not read:
+                                                                  # linear_down's output is a global phase of this circuit
         result = {
             "metric": "denoise-step images/sec, 8-qubit MNIST-28",
             "value": value,
@@ -854,7 +855,7 @@ def main(argv=None):
                 "achieved_standard_form": std_flop * args.batch * kspl / (kern_us * 1e-6) / 1e12,
                 "hbm_physical": {"io_bytes_per_launch": io_bytes, "GBps": io_bytes / (kern_us * 1e-6) / 1e9,
                                  "frac_of_peak": io_bytes / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                 "note": "images in/out only (exact count); weights and tables come from L2. The measured "
+                                 "note": "images out only (exact count); weights and tables come from L2. The measured "
                                          "2*FETCH_SIZE+WRITE_SIZE per launch is in the file `traffic_profile` names "
                                          "(separate --pmc passes of this command)"},
                 "hbm_equivalent": {"bytes_per_launch": alg_bytes, "GBps": hbm_eq, "x_peak": hbm_eq / HBM_PEAK_GBS,

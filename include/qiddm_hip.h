@@ -164,6 +164,14 @@ int qiddm_forward(const qiddm_circuit_t *circ, const void *inputs, int64_t batch
  * gate g, then 6*G_rot + 2*(block*n + wire) + (0:+, 1:-) for the input angle of
  * `wire` re-uploaded in `block`.  d/dtheta = (dots[+] - dots[-]) / 2 summed over
  * the batch (weights) or per sample (inputs; times enc_scale).  n_rounds must be 1.      */
+/* The same forward for the PROBABILITY nets with their `_post_process` fused into the store (reference
+ * nn/qdense.py:49-54, 443-448: `clamp(probs[:, :pixels] * pixels, 0, 1)` on the float64 the QNode returns):
+ * out (batch, post_cols) float64 = clamp((double)p[:, :post_cols] * post_scale, 0, 1) -- bit-identical to converting the
+ * probabilities to float64 first; the (batch, 2^n) matrix is never written.  measure = probs, n <= 10.           */
+int qiddm_forward_post(const qiddm_circuit_t *circ, const void *inputs, int64_t batch, int64_t in_ld,
+                       const void *gate_table, double *out, int64_t out_ld, int32_t post_cols, double post_scale,
+                       void *stream);
+
 int qiddm_forward_shifted(const qiddm_circuit_t *circ, const void *inputs, int64_t batch,
                           int64_t in_ld, const void *gate_table, const void *grad_out,
                           int64_t g_ld, int64_t first_replica, int64_t n_replicas, void *dots,

@@ -38,6 +38,7 @@ EXPORTS = (
     "qiddm_workspace_bytes",
     "qiddm_prepare_gates",
     "qiddm_forward",
+    "qiddm_forward_post",
     "qiddm_forward_shifted",
     "qiddm_adjoint_partials",
     "qiddm_backward_adjoint",
@@ -132,6 +133,8 @@ def _declare(lib):
     lib.qiddm_prepare_gates.argtypes = [P, vp, vp, vp]
     lib.qiddm_forward.restype = ctypes.c_int
     lib.qiddm_forward.argtypes = [P, vp, i64, i64, vp, vp, i64, vp, i64, vp]
+    lib.qiddm_forward_post.restype = ctypes.c_int
+    lib.qiddm_forward_post.argtypes = [P, vp, i64, i64, vp, vp, i64, ctypes.c_int32, ctypes.c_double, vp]
     lib.qiddm_forward_shifted.restype = ctypes.c_int
     lib.qiddm_forward_shifted.argtypes = [P, vp, i64, i64, vp, vp, i64, i64, i64, vp, vp, i64, vp]
     lib.qiddm_workspace_bytes.restype = i64

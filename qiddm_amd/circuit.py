@@ -238,6 +238,29 @@ def run_forward(circ: Circuit, inputs, angles: torch.Tensor, precision: str | No
     return out
 
 
+def run_forward_post(circ: Circuit, inputs, angles: torch.Tensor, post_cols: int, post_scale: float,
+                     precision: str | None = None) -> torch.Tensor:
+    """Probabilities of an n <= 10 circuit with the probability nets' ``_post_process`` fused into the store
+    (``qiddm_forward_post``): ``clamp(p[:, :post_cols] * post_scale, 0, 1)`` as float64, (B, post_cols).  No autograd."""
+    precision = precision or _default_precision
+    dtype = _DT[precision][1]
+    _require_device(angles, "the circuit weights")
+    device = angles.device
+    if circ.measure != "probs" or circ.n_qubits > 10:
+        raise ValueError("run_forward_post: probabilities of an n <= 10 circuit")
+    x, ld, circ2 = _prep_inputs(circ, inputs, dtype, device)
+    circ = circ2 or circ
+    if x is None:
+        raise ValueError("run_forward_post needs inputs")
+    table = prepare_gates(circ, angles, precision)
+    out = torch.empty(x.shape[0], post_cols, dtype=torch.float64, device=device)
+    cs = circ.c_struct(precision)
+    _capi.check(_capi.lib().qiddm_forward_post(ctypes.byref(cs), x.data_ptr(), x.shape[0], ld, table.data_ptr(),
+                                               out.data_ptr(), out.stride(0), int(post_cols), float(post_scale),
+                                               _stream_ptr(device)))
+    return out
+
+
 def _as_f64(t, device):
     return None if t is None else t.detach().to(device=device, dtype=torch.float64).contiguous()
 

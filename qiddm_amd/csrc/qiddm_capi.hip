@@ -705,6 +705,39 @@ int qiddm_prepare_gates(const qiddm_circuit_t* c, const double* angles, void* ga
   return QIDDM_OK;
 }
 
+int qiddm_forward_post(const qiddm_circuit_t* c, const void* inputs, int64_t batch, int64_t in_ld,
+                       const void* gate_table, double* out, int64_t out_ld, int32_t post_cols, double post_scale,
+                       void* stream) {
+  int rc = check_circuit(c);
+  if (rc != QIDDM_OK) return rc;
+  if (c->measure != QIDDM_MEAS_PROBS || c->n_qubits > QIDDM_MAX_QUBITS_FUSED)
+    return fail(QIDDM_ERR_UNSUPPORTED, "post-processed read-out: probabilities of an n <= %d circuit", QIDDM_MAX_QUBITS_FUSED);
+  if (batch < 0) return fail(QIDDM_ERR_INVALID, "batch=%lld < 0", (long long)batch);
+  if (post_cols < 1 || post_cols > (1 << c->n_qubits))
+    return fail(QIDDM_ERR_INVALID, "post_cols=%d outside 1 .. 2^n", post_cols);
+  if (out_ld < post_cols) return fail(QIDDM_ERR_INVALID, "out_ld=%lld < post_cols=%d", (long long)out_ld, post_cols);
+  if (batch == 0) return QIDDM_OK;
+  if (!gate_table || !out) return fail(QIDDM_ERR_INVALID, "gate_table/out is NULL");
+  if (c->encoding != QIDDM_ENC_NONE) {
+    if (!inputs) return fail(QIDDM_ERR_INVALID, "inputs is NULL but the encoding reads them");
+    if (in_ld < c->n_features)
+      return fail(QIDDM_ERR_INVALID, "in_ld=%lld < n_features=%d", (long long)in_ld, c->n_features);
+  }
+  qiddm::KScalars p = make_params(c);
+  Ptrs ptr;
+  ptr.inputs = inputs;
+  ptr.table = gate_table;
+  ptr.out = out;
+  p.in_ld = in_ld;
+  p.out_ld = out_ld;          // in float64 elements
+  p.batch = batch;
+  p.post_cols = post_cols;
+  p.post_scale = post_scale;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return c->dtype == QIDDM_F32 ? dispatch_n<float, false>(c->n_qubits, ptr, p, 0, st)
+                               : dispatch_n<double, false>(c->n_qubits, ptr, p, 0, st);
+}
+
 int qiddm_forward(const qiddm_circuit_t* c, const void* inputs, int64_t batch, int64_t in_ld,
                   const void* gate_table, void* out, int64_t out_ld, void* workspace,
                   int64_t workspace_bytes, void* stream) {

@@ -57,9 +57,27 @@ struct KScalars {
   int64_t in_ld, out_ld, g_ld, batch;
   int32_t first_replica;
   int32_t encoding, imprimitive, measure, n_rounds, n_blocks, sel_layers, n_features;
-  int32_t fold, pad_;  // fold: run the forward of a CZ circuit on the folded tables (host: can_fold())
+  int32_t fold;        // run the forward of a CZ circuit on the folded tables (host: can_fold())
+  int32_t post_cols;   // > 0 (probabilities only): `out` is float64 (B, post_cols) = clamp(p[:, :post_cols] * post_scale, 0, 1)
   double enc_scale, enc_offset, pad_with;
+  double post_scale;   // -- the `_post_process` of the probability nets (reference nn/qdense.py:49-54, 443-448)
 };
+
+// the probability read-out of a lane's amplitudes: raw (T), or post-processed float64 (KScalars::post_cols)
+template <typename T, int R, int LB>
+__device__ __forceinline__ void store_probs(const KScalars& p, T* __restrict__ out, int64_t sample, int sub, const T (&pr)[R]) {
+  if (p.post_cols > 0) {
+    double* __restrict__ o = reinterpret_cast<double*>(out) + sample * p.out_ld;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int k = (r << LB) | sub;
+      if (k < p.post_cols) o[k] = fmin(fmax((double)pr[r] * p.post_scale, 0.0), 1.0);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < R; ++r) out[sample * p.out_ld + ((r << LB) | sub)] = pr[r];
+  }
+}
 
 // ---------------------------------------------------------------------------
 // small math helpers
@@ -430,15 +448,18 @@ struct Engine {
   // false -- tables untouched -- when some |tan| exceeds 16 (cos(theta/2) within 3.6 degrees of zero): the caller then
   // runs the (cos, sin) path.  Every thread of the block calls it; it ends with a barrier.
   __device__ __forceinline__ bool tangent_fold(int n_layers_all, int layers_per_round) {
+    // (every wavefront looks at every entry and votes by ballot: the same answer in all of them without a word of static
+    //  LDS -- __syncthreads_or() brings 256 B of it, and the deep float64 circuits ask for all 160 KiB as dynamic LDS)
     bool bad = false;
-    for (int i = threadIdx.x; i < n_layers_all * N; i += blockDim.x) {
+    for (int i = threadIdx.x & (kWave - 1); i < n_layers_all * N; i += kWave) {
       const int l = i / N, w = i - l * N;
       if (l % layers_per_round == 0) continue;
       const T* e = s_gates_w + (size_t)l * S::kFoldStride + 2 * w;
       const T c = e[0], sn = e[1];
       bad |= !(fabs(sn) <= (T)16 * fabs(c));
     }
-    if (__syncthreads_or(bad)) return false;
+    if (__ballot(bad) != 0) return false;
+    __syncthreads();   // (all votes are cast before anyone rewrites the entries)
     for (int i = threadIdx.x; i < n_layers_all * LPS; i += blockDim.x) {
       const int l = i / LPS, k = i - l * LPS;
       if (l % layers_per_round == 0) continue;
@@ -1207,10 +1228,7 @@ __global__ __launch_bounds__(4 * kWave) void circuit_kernel(const T* __restrict_
 
     if constexpr (!SHIFT) {
       if (p.measure == 0) {
-        if (valid) {
-#pragma unroll
-          for (int r = 0; r < R; ++r) out[sample * p.out_ld + ((r << LB) | sub)] = pr[r];
-        }
+        if (valid) store_probs<T, R, LB>(p, out, sample, sub, pr);
       } else {
         T v = 0;  // arithmetic select (see half_angle_sincos)
 #pragma unroll
@@ -1276,10 +1294,7 @@ __global__ __launch_bounds__(4 * kWave, (sizeof(T) == 4 ? 2 : 1)) void circuit_f
     if (tan_ok) eng.template run_folded<true>(p, xs, result, pr);
     else eng.template run_folded<false>(p, xs, result, pr);
     if (p.measure == 0) {
-      if (valid) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) out[sample * p.out_ld + ((r << LB) | sub)] = pr[r];
-      }
+      if (valid) store_probs<T, R, LB>(p, out, sample, sub, pr);
     } else {
       T v = 0;  // arithmetic select (see half_angle_sincos)
 #pragma unroll

@@ -180,6 +180,15 @@ class QDenseUndirected_old(_QuantumNet):
     def forward(self, x):
         b = x.shape[0]
         flat = x.reshape(b, self.pixels)                     # "b 1 w h -> b (w h)"
+        if self._fused_rounds_ok() and self.wires <= 10 and flat.is_cuda and \
+                type(self)._circuit in (QDenseUndirected_old._circuit, QDenseUndirected_old_noise._circuit) and \
+                type(self)._post_process is QDenseUndirected_old._post_process:
+            # inference: embedding, circuit and post-processing in one launch (no (B, 2^n) probability matrix)
+            circ = _c.Circuit(n_qubits=self.wires, encoding="amplitude", imprimitive="CNOT", measure="probs",
+                              n_rounds=1, n_blocks=1, sel_layers=self.qdepth, n_features=self.pixels, pad_with=0.1)
+            angles = self._weight_map(self.weights.detach()).reshape(circ.angles_shape)
+            out = _c.run_forward_post(circ, flat, angles, self.pixels, float(self.pixels))
+            return out.reshape(b, 1, self.width, self.height)
         out = self._post_process(self.qnode(flat))
         return out.reshape(b, 1, self.width, self.height)
 
@@ -404,6 +413,10 @@ class differN_noise(_QuantumNet):
         if self._fused_rounds_ok():
             circ = _c.Circuit(n_qubits=self.wires, encoding="rz", imprimitive="CZ", measure="probs",
                               n_rounds=self.N, n_blocks=self.spectrum_layer, sel_layers=2)
+            if self.wires <= 10 and type(self)._post_process is differN_noise._post_process:
+                # inference: all rounds AND the post-processing in one launch (the (B, 2^n) probabilities are never written)
+                out = _c.run_forward_post(circ, red, self.weights, self.pixels, float(self.pixels))
+                return out.reshape(red.shape[0], 1, self.width, self.height)
             p = _c.execute(circ, red, self.weights).to(torch.float64)
         else:
             p = red

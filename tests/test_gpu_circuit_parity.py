@@ -198,3 +198,33 @@ def test_lean_folded_forward_large_batches(n, meas, N, L, S, precision):
         assert torch.allclose(got.sum(1), torch.ones(batch, dtype=torch.float64), atol=1e-5)
     else:
         assert got.abs().max() <= 1 + 1e-5
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+@pytest.mark.parametrize("n,enc,imp,N,L,S,B,cols", [(10, "rz", "CZ", 2, 9, 2, 1024, 784),      # C3's differN_noise(28, 9, 2)
+                                                    (10, "rz", "CZ", 1, 2, 2, 37, 1024),
+                                                    (10, "rz", "CZ", 2, 3, 2, 3000, 784),      # > 1024 sample groups
+                                                    (6, "rz", "CZ", 2, 4, 2, 50, 64),
+                                                    (8, "rz", "CZ", 1, 3, 2, 5000, 200),       # the lean folded kernel at n = 8
+                                                    (10, "amplitude", "CNOT", 1, 1, 5, 33, 784),  # QDenseUndirected family
+                                                    (3, "amplitude", "CNOT", 1, 1, 2, 9, 5)])
+def test_forward_post_is_the_post_processed_forward(n, enc, imp, N, L, S, B, cols, precision):
+    """qiddm_forward_post == clamp(float64(qiddm_forward)[:, :cols] * cols, 0, 1), bit for bit (the same kernels with the
+    reference's `_post_process`, nn/qdense.py:49-54 / 443-448, fused into the store), and == the oracle."""
+    from qiddm_amd.circuit import Circuit, run_forward, run_forward_post
+    g = torch.Generator().manual_seed(n * 100 + B)
+    feats = cols if enc == "amplitude" else n
+    circ = Circuit(n_qubits=n, encoding=enc, imprimitive=imp, measure="probs", n_rounds=N, n_blocks=L, sel_layers=S,
+                   n_features=feats if enc == "amplitude" else 0, pad_with=0.1)
+    w = torch.randn(circ.angles_shape, generator=g, dtype=torch.float64) * 0.5
+    x = torch.rand(B, feats, generator=g, dtype=torch.float64) if enc == "amplitude" else \
+        torch.randn(B, n, generator=g, dtype=torch.float64)
+    raw = run_forward(circ, x.cuda(), w.cuda(), precision)
+    want = torch.clamp(raw.double()[:, :cols] * float(cols), 0, 1)
+    got = run_forward_post(circ, x.cuda(), w.cuda(), cols, float(cols), precision)
+    assert got.dtype == torch.float64 and got.shape == (B, cols)
+    assert torch.equal(got, want)
+    spec = oc.Spec(n=n, encoding=enc, imprimitive=imp, measure="probs", pad_with=0.1)
+    ref = torch.clamp(oc.run_circuit(spec, x[:64], w)[:, :cols] * cols, 0, 1)
+    tol = 1e-9 if precision == "f64" else 2e-5 * cols
+    assert (got[:64].cpu() - ref).abs().max().item() < tol
