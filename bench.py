@@ -494,9 +494,9 @@ def secondary_c3_circuits(dev, out):
         tag = "C3_differN_noise(28,9,2)_b1024"
         out[f"denoise_images_per_s_{tag}"] = batch / (us * 1e-6)
         out[f"gate_apps_per_s_{tag}"] = batch * 900 / (us * 1e-6)
-        flop = 2 * 18 * 1024 * (6 + 6 * 10)       # folded tables: phase multiply + 10 real RYs per amplitude and layer
-        out[f"roofline_{tag}"] = _valu_block(flop * batch, us, "qiddm::circuit_kernel<float, 10, false>",
-                                             "circuit + clamp(p * 784): forward_from_reduced, one wavefront per sample")
+        flop = 2 * 17 * 1024 * (6 + 4 * 10)       # tangent-form layers: phase multiply + 10 RYs (4 flop) per amplitude
+        out[f"roofline_{tag}"] = _valu_block(flop * batch, us, "qiddm::circuit_folded_kernel<float, 10>",
+                                             "circuit + clamp(p * 784) in one launch (qiddm_forward_post), one wavefront per sample")
     except Exception as e:  # pragma: no cover
         out["error_C3_differN_noise"] = repr(e)
     try:

@@ -239,7 +239,7 @@ def run_forward(circ: Circuit, inputs, angles: torch.Tensor, precision: str | No
 
 
 def run_forward_post(circ: Circuit, inputs, angles: torch.Tensor, post_cols: int, post_scale: float,
-                     precision: str | None = None) -> torch.Tensor:
+                     precision: str | None = None, table: torch.Tensor | None = None) -> torch.Tensor:
     """Probabilities of an n <= 10 circuit with the probability nets' ``_post_process`` fused into the store
     (``qiddm_forward_post``): ``clamp(p[:, :post_cols] * post_scale, 0, 1)`` as float64, (B, post_cols).  No autograd."""
     precision = precision or _default_precision
@@ -252,7 +252,8 @@ def run_forward_post(circ: Circuit, inputs, angles: torch.Tensor, post_cols: int
     circ = circ2 or circ
     if x is None:
         raise ValueError("run_forward_post needs inputs")
-    table = prepare_gates(circ, angles, precision)
+    if table is None:
+        table = prepare_gates(circ, angles, precision)
     out = torch.empty(x.shape[0], post_cols, dtype=torch.float64, device=device)
     cs = circ.c_struct(precision)
     _capi.check(_capi.lib().qiddm_forward_post(ctypes.byref(cs), x.data_ptr(), x.shape[0], ld, table.data_ptr(),

@@ -84,6 +84,19 @@ class _QuantumNet(nn.Module):
             self._sampler_tables_cache = cached
         return cached[1]
 
+    def _gate_table(self, circ, weights, angle_map=None):
+        """Gate table of ``circ`` for the current weights (``qiddm_prepare_gates``), rebuilt only when they (or the
+        precision) changed; ``angle_map`` is applied to the weights first (``qw_map.tanh`` / ``torch.tanh``)."""
+        stamp = (weights._version, weights.data_ptr(), str(weights.device), _c._default_precision, circ.angles_shape,
+                 circ.n_features)
+        cached = getattr(self, "_gate_table_cache", None)
+        if cached is None or cached[0] != stamp:
+            ang = weights.detach() if angle_map is None else angle_map(weights.detach())
+            ang = ang.reshape(circ.angles_shape)
+            cached = (stamp, ang, _c.prepare_gates(circ, ang, _c._default_precision))
+            self._gate_table_cache = cached
+        return cached[1], cached[2]
+
     def _lean_sampler_tables(self, circ, angles, lin_down, lin_up):
         """Tables of the lean 8- / 6-qubit sampler (goal "data"), rebuilt only when the weights, the two linears or the
         precision changed; None when that kernel does not apply (then the general sampler runs)."""
@@ -186,8 +199,8 @@ class QDenseUndirected_old(_QuantumNet):
             # inference: embedding, circuit and post-processing in one launch (no (B, 2^n) probability matrix)
             circ = _c.Circuit(n_qubits=self.wires, encoding="amplitude", imprimitive="CNOT", measure="probs",
                               n_rounds=1, n_blocks=1, sel_layers=self.qdepth, n_features=self.pixels, pad_with=0.1)
-            angles = self._weight_map(self.weights.detach()).reshape(circ.angles_shape)
-            out = _c.run_forward_post(circ, flat, angles, self.pixels, float(self.pixels))
+            angles, table = self._gate_table(circ, self.weights, self._weight_map)
+            out = _c.run_forward_post(circ, flat, angles, self.pixels, float(self.pixels), table=table)
             return out.reshape(b, 1, self.width, self.height)
         out = self._post_process(self.qnode(flat))
         return out.reshape(b, 1, self.width, self.height)
@@ -415,7 +428,8 @@ class differN_noise(_QuantumNet):
                               n_rounds=self.N, n_blocks=self.spectrum_layer, sel_layers=2)
             if self.wires <= 10 and type(self)._post_process is differN_noise._post_process:
                 # inference: all rounds AND the post-processing in one launch (the (B, 2^n) probabilities are never written)
-                out = _c.run_forward_post(circ, red, self.weights, self.pixels, float(self.pixels))
+                ang, table = self._gate_table(circ, self.weights)
+                out = _c.run_forward_post(circ, red, ang, self.pixels, float(self.pixels), table=table)
                 return out.reshape(red.shape[0], 1, self.width, self.height)
             p = _c.execute(circ, red, self.weights).to(torch.float64)
         else:

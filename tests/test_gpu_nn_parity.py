@@ -431,3 +431,26 @@ def test_hip_bilinear_upsample_matches_torch(shape):
     (yb * g).sum().backward()
     assert torch.allclose(ya, yb, rtol=1e-13, atol=1e-13), (ya - yb).abs().max()
     assert torch.allclose(xa.grad, xb.grad, rtol=1e-12, atol=1e-12), (xa.grad - xb.grad).abs().max()
+
+
+def test_probability_nets_fused_post_processing_tracks_weight_updates():
+    """differN_noise / QDenseUndirected_old_noise at inference: circuit + `_post_process` in one launch on a gate table
+    cached per weights -- equal to the oracle before and after an in-place weight update (the cache key is the version)."""
+    from qiddm_amd import nn
+    torch.manual_seed(5)
+    net = nn.differN_noise(8, 3, 2).to(DEV).eval()
+    red = torch.randn(9, 6, device=DEV)
+    with torch.no_grad():
+        for _ in range(2):
+            got = net.forward_from_reduced(red).cpu()
+            ref = oc.differn_from_reduced(red.cpu(), net.weights.detach().cpu(), (8, 8))
+            assert torch.allclose(got, ref, atol=2e-3), (got - ref).abs().max()
+            net.weights.mul_(1.3)
+    net2 = nn.QDenseUndirected_old_noise(4, 8).to(DEV).eval()
+    x = torch.rand(5, 1, 8, 8, dtype=torch.float64, device=DEV)
+    with torch.no_grad():
+        for _ in range(2):
+            got = net2(x).cpu()
+            ref = oc.qdense_undirected_forward(x.cpu(), net2.weights.detach().cpu().double(), (8, 8), weight_map="tanh")
+            assert torch.allclose(got, ref, atol=2e-3), (got - ref).abs().max()
+            net2.weights.add_(0.2)
