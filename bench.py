@@ -799,102 +799,109 @@ def main(argv=None):
             train = dp_train_measurement(dev, args.batch, world, rank)
         except Exception as e:  # pragma: no cover - must not cost the headline line
             train = {"train_error": repr(e)}
+    rank0_error = None
     if rank == 0:
-        plan = launch_plan(args.steps, spl)
-        kspl = max(set(plan), key=plan.count) if plan else spl     # the launch shape the timed region is made of
-        kern_us = time_dominant_kernel(diff, x0.to(dev), kspl)
-        circ = diff.net._circuit_descriptor()
-        g_per_sample = circ.gate_count()
-        alg_bytes = circ.algorithmic_bytes_per_sample("f32") * args.batch * kspl   # per launch
-        hbm_eq = alg_bytes / (kern_us * 1e-6) / 1e9
-        flop = lean_flop(N_QUBITS, QDEPTH, 1, IMG * IMG, False)   # what the kernel executes (tangent-form layers)
-        std_flop = dense_flop(N_QUBITS, QDEPTH, 1, IMG * IMG)     # the same circuit in the (c, s) form of round 2
-        valu_tf = flop * args.batch * kspl / (kern_us * 1e-6) / 1e12
-        io_bytes = kspl * args.batch * IMG * IMG * 8              # one image out per step (exact); the input image is not read:
-                                                                  # linear_down's output is a global phase of this circuit
-        result = {
-            "metric": "denoise-step images/sec, 8-qubit MNIST-28",
-            "value": value,
-            "unit": "images/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "repeats": repeats,
-            "timed_region_s": elapsed,
-            "ms_per_step": elapsed / total_steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": "MNIST 28x28, 8-qubit qdense QNN_noise(784,8,14), batch 256 per GPU, "
-                                   "one Diffusion.sample body (goal=data) per step",
-                       "batch_per_gpu": args.batch, "global_batch": world * args.batch,
-                       "n_qubits": N_QUBITS, "gates_per_sample": g_per_sample,
-                       "launch": "eager" if args.no_graph else
-                       f"hipGraph replay; launches of the fused sampler hold {plan} steps for K={args.steps}; the K steps "
-                       f"are repeated {repeats}x inside the timed region"
-                       + (f", {Runner.GROUP} consecutive K-step launches per graph replay" if len(plan) == 1 else ""),
-                       "backend": ("gloo (one-GPU rehearsal)" if args.rehearse_on_one_gpu else "nccl (RCCL)") if world > 1 else "none",
-                       "parallelism": f"shard{world}"},
-            "gate_apps_per_s": value * g_per_sample,
-            "roofline": {
-                # The statevector of an 8-qubit sample (2 KiB) lives in the registers of four wavefronts: the kernel
-                # is bounded by instruction issue / latency on the vector ALU, not by HBM.  frac = executed VALU flop
-                # / f32 vector peak; the counters behind "latency-bound" are in profiles/ (SQ_* passes).
-                "bound": "valu", "achieved": valu_tf, "peak": VALU_PEAK_TF, "unit": "TFLOP/s",
-                "frac": valu_tf / VALU_PEAK_TF,
-                "traffic": None,
-                "traffic_profile": TRAFFIC_PROFILE,
-                "kernel": HEADLINE_KERNEL.format("float"),
-                "steps_per_launch": kspl,
-                "kernel_avg_us": kern_us,
-                "kernel_us_per_step": kern_us / kspl,
-                "executed_flop_per_sample_step": flop,
-                "standard_form_flop_per_sample_step": std_flop,
-                "achieved_standard_form": std_flop * args.batch * kspl / (kern_us * 1e-6) / 1e12,
-                "hbm_physical": {"io_bytes_per_launch": io_bytes, "GBps": io_bytes / (kern_us * 1e-6) / 1e9,
-                                 "frac_of_peak": io_bytes / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                 "note": "images out only (exact count); weights and tables come from L2. The measured "
-                                         "2*FETCH_SIZE+WRITE_SIZE per launch is in the file `traffic_profile` names "
-                                         "(separate --pmc passes of this command)"},
-                "hbm_equivalent": {"bytes_per_launch": alg_bytes, "GBps": hbm_eq, "x_peak": hbm_eq / HBM_PEAK_GBS,
-                                   "note": "SURVEY 8d accounting, (G+1/2)*16*2^n B per sample: what a one-sweep-per-gate "
-                                           "HBM simulator would move. Not a roofline fraction: the slab never leaves "
-                                           "the registers"},
-                "note": HEADLINE_NOTE,
-            },
-        }
-        if train:
-            result.update(train)
-        if f64 is not None:
-            result["f64"] = f64
-        if world == 1:
-            try:
-                result["roofline_c5"] = c5_roofline(dev)
-            except Exception as e:  # pragma: no cover
-                result["roofline_c5"] = {"error": repr(e)}
-        if not args.no_secondary and world == 1:
-            result["secondary"] = secondary_measurements(dev, args.batch)
-        if not args.no_cpu_baseline and world == 1:
-            cb = cpu_baseline(diff, x0, args.cpu_seconds)
-            v, sample = cb["batched"]
-            vl, sample_l = cb["per_sample_loop"]
-            result["cpu_baseline"] = {
-                "value": v, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": sample + " (oracle: batched complex128 per-gate torch update)",
-                "gate_apps_per_s": v * g_per_sample,
-                "dtype": "f64",
-                "per_sample_loop": {"value": vl, "unit": "images/s", "sample": sample_l +
-                                    " (the reference's own QNN_noise.forward shape, nn/qdense.py:278-281)"}}
-            if f64 is not None and "images_per_s" in f64:
-                # like for like: the reference's precision on both sides, both from a timed region
-                result["speedup_vs_cpu_same_precision"] = f64["images_per_s"] / v
-            result["speedup_vs_cpu_f32_gpu"] = value / v
-        print(json.dumps(result), flush=True)
+        try:
+            plan = launch_plan(args.steps, spl)
+            kspl = max(set(plan), key=plan.count) if plan else spl     # the launch shape the timed region is made of
+            kern_us = time_dominant_kernel(diff, x0.to(dev), kspl)
+            circ = diff.net._circuit_descriptor()
+            g_per_sample = circ.gate_count()
+            alg_bytes = circ.algorithmic_bytes_per_sample("f32") * args.batch * kspl   # per launch
+            hbm_eq = alg_bytes / (kern_us * 1e-6) / 1e9
+            flop = lean_flop(N_QUBITS, QDEPTH, 1, IMG * IMG, False)   # what the kernel executes (tangent-form layers)
+            std_flop = dense_flop(N_QUBITS, QDEPTH, 1, IMG * IMG)     # the same circuit in the (c, s) form of round 2
+            valu_tf = flop * args.batch * kspl / (kern_us * 1e-6) / 1e12
+            io_bytes = kspl * args.batch * IMG * IMG * 8              # one image out per step (exact); the input image is not read:
+                                                                      # linear_down's output is a global phase of this circuit
+            result = {
+                "metric": "denoise-step images/sec, 8-qubit MNIST-28",
+                "value": value,
+                "unit": "images/s",
+                "n_gpus": world,
+                "steps": args.steps,
+                "warmup": args.warmup,
+                "repeats": repeats,
+                "timed_region_s": elapsed,
+                "ms_per_step": elapsed / total_steps * 1e3,
+                "higher_is_better": True,
+                "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": "f32",
+                "data": "synthetic",
+                "config": {"workload": "MNIST 28x28, 8-qubit qdense QNN_noise(784,8,14), batch 256 per GPU, "
+                                       "one Diffusion.sample body (goal=data) per step",
+                           "batch_per_gpu": args.batch, "global_batch": world * args.batch,
+                           "n_qubits": N_QUBITS, "gates_per_sample": g_per_sample,
+                           "launch": "eager" if args.no_graph else
+                           f"hipGraph replay; launches of the fused sampler hold {plan} steps for K={args.steps}; the K steps "
+                           f"are repeated {repeats}x inside the timed region"
+                           + (f", {Runner.GROUP} consecutive K-step launches per graph replay" if len(plan) == 1 else ""),
+                           "backend": ("gloo (one-GPU rehearsal)" if args.rehearse_on_one_gpu else "nccl (RCCL)") if world > 1 else "none",
+                           "parallelism": f"shard{world}"},
+                "gate_apps_per_s": value * g_per_sample,
+                "roofline": {
+                    # The statevector of an 8-qubit sample (2 KiB) lives in the registers of four wavefronts: the kernel
+                    # is bounded by instruction issue / latency on the vector ALU, not by HBM.  frac = executed VALU flop
+                    # / f32 vector peak; the counters behind "latency-bound" are in profiles/ (SQ_* passes).
+                    "bound": "valu", "achieved": valu_tf, "peak": VALU_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": valu_tf / VALU_PEAK_TF,
+                    "traffic": None,
+                    "traffic_profile": TRAFFIC_PROFILE,
+                    "kernel": HEADLINE_KERNEL.format("float"),
+                    "steps_per_launch": kspl,
+                    "kernel_avg_us": kern_us,
+                    "kernel_us_per_step": kern_us / kspl,
+                    "executed_flop_per_sample_step": flop,
+                    "standard_form_flop_per_sample_step": std_flop,
+                    "achieved_standard_form": std_flop * args.batch * kspl / (kern_us * 1e-6) / 1e12,
+                    "hbm_physical": {"io_bytes_per_launch": io_bytes, "GBps": io_bytes / (kern_us * 1e-6) / 1e9,
+                                     "frac_of_peak": io_bytes / (kern_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                     "note": "images out only (exact count); weights and tables come from L2. The measured "
+                                             "2*FETCH_SIZE+WRITE_SIZE per launch is in the file `traffic_profile` names "
+                                             "(separate --pmc passes of this command)"},
+                    "hbm_equivalent": {"bytes_per_launch": alg_bytes, "GBps": hbm_eq, "x_peak": hbm_eq / HBM_PEAK_GBS,
+                                       "note": "SURVEY 8d accounting, (G+1/2)*16*2^n B per sample: what a one-sweep-per-gate "
+                                               "HBM simulator would move. Not a roofline fraction: the slab never leaves "
+                                               "the registers"},
+                    "note": HEADLINE_NOTE,
+                },
+            }
+            if train:
+                result.update(train)
+            if f64 is not None:
+                result["f64"] = f64
+            if world == 1:
+                try:
+                    result["roofline_c5"] = c5_roofline(dev)
+                except Exception as e:  # pragma: no cover
+                    result["roofline_c5"] = {"error": repr(e)}
+            if not args.no_secondary and world == 1:
+                result["secondary"] = secondary_measurements(dev, args.batch)
+            if not args.no_cpu_baseline and world == 1:
+                cb = cpu_baseline(diff, x0, args.cpu_seconds)
+                v, sample = cb["batched"]
+                vl, sample_l = cb["per_sample_loop"]
+                result["cpu_baseline"] = {
+                    "value": v, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+                    "sample": sample + " (oracle: batched complex128 per-gate torch update)",
+                    "gate_apps_per_s": v * g_per_sample,
+                    "dtype": "f64",
+                    "per_sample_loop": {"value": vl, "unit": "images/s", "sample": sample_l +
+                                        " (the reference's own QNN_noise.forward shape, nn/qdense.py:278-281)"}}
+                if f64 is not None and "images_per_s" in f64:
+                    # like for like: the reference's precision on both sides, both from a timed region
+                    result["speedup_vs_cpu_same_precision"] = f64["images_per_s"] / v
+                result["speedup_vs_cpu_f32_gpu"] = value / v
+            print(json.dumps(result), flush=True)
+
+        except BaseException as e:   # the other ranks wait in the barrier below: reach it, then re-raise
+            rank0_error = e
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if rank0_error is not None:
+        raise rank0_error
 
 
 if __name__ == "__main__":
