@@ -13,7 +13,8 @@
 //     depth 1 per lane-bit gate instead of 3 (dpp mov, wait state, packed fma behind a packed multiply).  The factors c
 //     of a layer commute with everything and are folded into that layer's phase table, so they cost nothing.
 //   * the row-crossing bits 4 / 5 keep the permlane swap of (re, im) (qsim_quad.h), with the 2 x 2 in tangent form:
-//     swap, one fma per member, swap -- depth 3 instead of 4.
+//     swap, one fma per member, swap -- depth 3 instead of 4; at 8 qubits the two gates share their swaps and never swap
+//     back (the LDS exchange that follows stores into natural slots): depth 4 for both.
 //   * the wave-bit 4 x 4 in tangent form: own + k1 p1 + k2 p2 + k3 p3 with per-wave k = +-t6, +-t7, their product;
 //     nothing to multiply before the barrier.
 //   * per-layer data (this thread's phase, eight tangents) is read one layer ahead while the exchange is in flight,
@@ -259,6 +260,10 @@ __global__ __launch_bounds__(256) void dense_lean_kernel(
   }
   const uint32_t kbase = (N == 8 ? ((uint32_t)wv << 6) : 0u) | (uint32_t)llane;
   const int slot = N == 8 ? tid : lane;   // this thread's entry of a per-amplitude table
+  // where this lane's two values go after the un-swapped bit-5 / bit-4 gates (8 qubits; elements of T inside the wave's
+  // 64 (re, im) slots): lanes 0-15 hold re[l], re[l+16]; 16-31 re[l+16], re[l+32]; 32-47 im[l-32], im[l-16];
+  // 48-63 im[l-16], im[l] -- first value at 2 * index + component, second 16 amplitudes (32 elements) further
+  const int scatter_off = 2 * (lane < 16 ? lane : lane < 32 ? lane + 16 : lane < 48 ? lane - 32 : lane - 16) + (lane >> 5);
   T pm[8];   // +-1 by this thread's index bit
 #pragma unroll
   for (int q = 0; q < 8; ++q) pm[q] = ((kbase >> q) & 1u) ? (T)1 : (T)-1;
@@ -412,20 +417,37 @@ __global__ __launch_bounds__(256) void dense_lean_kernel(
           __builtin_amdgcn_sched_barrier(0);
           a = cmul2<T>(cur.ph, a, times_i<T>(a));
           ry_t_dpp4(a, cur.ts[0], cur.ts[1], cur.ts[2], cur.ts[3]);
-          ry_t_swap<5, T>(a, cur.t5);
-          derive_layer(nxt, raw, li + 1);   // (the reads were issued ~100 cycles ago)
-          ry_t_swap<4, T>(a, cur.t4);
-          if constexpr (N == 8) {   // the two wave bits: one real 4 x 4 through LDS
+          if constexpr (N == 8) {
+            // Bits 5 and 4 WITHOUT swapping back: after the permlane32 swap a lane holds (low, high) members of bit 5 of
+            // one component; a permlane16 swap of THAT puts (low, high) members of bit 4 into every lane (rows 0 / 1 of
+            // the real parts, rows 2 / 3 of the imaginary parts -- table at s_scatter below), so both 2 x 2 run
+            // in-register.  The way back is free: the wave-bit exchange goes through LDS anyway, so the two values are
+            // stored straight into their amplitudes' natural (re, im) slots (`ds_write2_b32`, second slot 16 amplitudes
+            // up) and every thread reads its own amplitude back next to the three partners'.  Two swaps (and their wait
+            // states) less in the chain of every layer.
+            T lo = a.x, hi = a.y;
+            swap_parts<5>(lo, hi);
+            T nlo = fma(-cur.t5, hi, lo), nhi = fma(cur.t5, lo, hi);
+            derive_layer(nxt, raw, li + 1);   // (the reads were issued ~100 cycles ago)
+            swap_parts<4>(nlo, nhi);
+            const T vx = fma(-cur.t4, nhi, nlo), vy = fma(cur.t4, nlo, nhi);
             C* buf = s_slab + (size_t)xbuf_parity * (4 * kWave);
             xbuf_parity ^= 1;
-            buf[wv * kWave + lane] = a;
+            T* slot = reinterpret_cast<T*>(buf + wv * kWave) + scatter_off;
+            slot[0] = vx;
+            slot[32] = vy;
             __syncthreads();
+            const C p0 = buf[wv * kWave + lane];
             const C p1 = buf[(wv ^ 1) * kWave + lane];
             const C p2 = buf[(wv ^ 2) * kWave + lane];
             const C p3 = buf[(wv ^ 3) * kWave + lane];
-            const C o = __builtin_elementwise_fma(bcast<T>(cur.k1), p1, a);
+            const C o = __builtin_elementwise_fma(bcast<T>(cur.k1), p1, p0);
             const C t = __builtin_elementwise_fma(bcast<T>(cur.k3), p3, bcast<T>(cur.k2) * p2);
             a = o + t;
+          } else {
+            ry_t_swap<5, T>(a, cur.t5);
+            derive_layer(nxt, raw, li + 1);   // (the reads were issued ~100 cycles ago)
+            ry_t_swap<4, T>(a, cur.t4);
           }
         };
         if constexpr (LPR > 0) {
