@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "qsim_lean.h"

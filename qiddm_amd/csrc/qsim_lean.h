@@ -24,6 +24,14 @@
 //     this step -- an n x n product built once per weights (lean_tables_kernel).  Where the angles cannot reach the
 //     state at all (one block per round: RZ on |0..0> is a global phase, finding F2) they are not computed.
 //
+// Tried on top and dropped (round 3): the tail of a step (|amplitude|^2, signed sums, linear_up, stores: ~1 250 of ~6 900
+// cycles, and independent of the next step's circuit when there is no re-upload) overlapped with the next step's layers
+// (a) as pieces placed in the two exchange windows of the first five layers -- behind in-order issue a wave that waits for
+// its side chain waits with its main chain too: the layers grew by what the tail had cost (6 924 -> 6 492 cycles per step);
+// (b) on a fifth, helper wavefront sharing SIMD 0 with wave 0, applying the last layer's 4 x 4 itself and owning all 256
+// probabilities -- correct, but every barrier now waits for five waves and wave 0 shares its issue: 3.35 -> 3.51 us per
+// step in float32 (4.28 -> 4.11 in complex128).
+//
 // The tangent form needs cos(theta / 2) away from zero: the table builder records max |t|; the host routes weights with
 // max |t| > kLeanMaxTan to dense_quad_kernel (qiddm_dense_sample_lean_check).  Shipped checkpoints have |theta / 2| < 0.9.
 #pragma once
@@ -297,6 +305,7 @@ __global__ __launch_bounds__(256) void dense_lean_kernel(
   double ev[8];   // <Z_w> of the last round (N used): linear_up's input and the next step's composite input
 #pragma unroll
   for (int j = 0; j < 8; ++j) ev[j] = 0.0;
+
   for (int64_t sample = blockIdx.x; sample < p.batch; sample += gridDim.x) {
     for (int step = 0; step < d.n_steps; ++step) {
       const bool st = stamp && step == 1;
