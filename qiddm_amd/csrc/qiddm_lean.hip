@@ -89,7 +89,8 @@ int dispatch_lean_n(const double* x, const double* wd, const double* bd, const d
     return reup ? launch_lean<T, N, 8, true, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st)
                 : launch_lean<T, N, 8, false, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
   if (reup) {
-    if (lpr == kReupLpr) return launch_lean<T, N, 4, true, kReupLpr>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+    if (lpr == kReupLpr && p.sel_layers == 2)
+      return launch_lean<T, N, 4, true, kReupLpr>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
     return launch_lean<T, N, 4, true, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
   }
   if (lpr == 14) return launch_lean<T, N, 4, false, 14>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);

@@ -213,7 +213,8 @@ struct LeanLayer {
 // REUP: the circuit re-uploads its data angles (n_blocks > 1); without it the angles never reach the state and no
 //       angle code is compiled at all (no branch in the layer either: a taken branch costs a lone wavefront ~50 cycles).
 // LPR:  layers per round as a compile-time constant (fully unrolled layer sequence; 14 = the flagship QNN_noise(784, 8,
-//       14), 12 = the LL-style (6 blocks x 2)), or 0 for a runtime count (loop over pairs of layers).
+//       14), 12 / 28 = the LL-style (6 / 14 blocks x 2) -- with REUP a compiled-in count also means TWO layers per
+//       block), or 0 for a runtime count (loop over pairs of layers, block starts by comparison).
 template <typename T, int N, int PPT, bool REUP, int LPR>
 __global__ __launch_bounds__(256) void dense_lean_kernel(
     const double* __restrict__ x, const double* __restrict__ wd, const double* __restrict__ bd,
@@ -396,7 +397,11 @@ __global__ __launch_bounds__(256) void dense_lean_kernel(
         // not branched on: the product rides in empty issue slots a layer ahead)
         auto derive_layer = [&](LeanLayer<T>& c, const Raw& r, int li) {
           c.ph = r.ph;
-          if constexpr (REUP) {
+          if constexpr (REUP && LPR > 0) {
+            // layers per round compiled in => two SEL layers per block (every LL / PL net of the reference; the host
+            // checks): block starts are the even layers, a constant after unrolling -- no select, no multiply elsewhere
+            if (li % 2 == 0 && li < LPR) c.ph = cmul2<T>(dx, r.ph, times_i<T>(r.ph));
+          } else if constexpr (REUP) {
             const bool up = li == next_upload;
             if (up) next_upload += p.sel_layers;     // (scalar select, no branch)
             const C dxs = C{up ? dx.x : (T)1, up ? dx.y : (T)0};
