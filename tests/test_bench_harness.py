@@ -129,6 +129,13 @@ def test_dense_flop_matches_the_headline_count():
     assert bench.dense_flop(8, 14, 1, 784) == 13 * 256 * 54 + 8 * 256 + 2 * 8 * 256 + 2 * 2 * 784 * 8 == 210944
 
 
+def test_lean_flop_is_the_tangent_form_count():
+    # 13 simulated layers x 256 amplitudes x (6 + 8 * 4) + read-out 256 * (3 + 8) + linear_up 2 * 784 * 8
+    assert bench.lean_flop(8, 14, 1, 784, False) == 13 * 256 * 38 + 256 * 11 + 2 * 784 * 8 == 141824
+    assert bench.lean_flop(8, 12, 2, 784, True) == 2 * (11 * 256 * 38 + 256 * 11) + 2 * 784 * 8 + 128
+    assert bench.lean_flop(8, 14, 1, 784, False) < bench.dense_flop(8, 14, 1, 784)
+
+
 # ---- the N-rank self-launch -----------------------------------------------------------------------------------------
 def _dry(*argv, env=None):
     e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
