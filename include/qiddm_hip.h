@@ -253,11 +253,12 @@ int64_t qiddm_dense_sample_tables_bytes(const qiddm_circuit_t *circ);
 int qiddm_dense_sample_prepare(const qiddm_circuit_t *circ, const double *angles, void *tables, void *stream);
 
 /* ---- lean sampling loop of the 8- and 6-qubit dense nets (qsim_lean.h) --------------------------------------------
- * The same n_steps bodies of Diffusion.sample for prediction_goal "data" (post_mode 0: x <- net(x), reference
- * src/models.py:127-129) on 8 or 6 wires / CZ rings / RZ encoding / <Z>, with every RY in tangent form (one fused
- * cross-lane multiply-add per gate) and linear_down composed with linear_up into an n x n map of the previous step's
- * <Z> (W_down is only read for the first step, and not at all when the circuit has one block per round: the data
- * angles are then a global phase).  Tables: qiddm_dense_sample_lean_tables_bytes(circ) bytes, written once per
+ * The same n_steps bodies of Diffusion.sample (post_mode / noise_factor as for qiddm_dense_sample, reference
+ * src/models.py:127-134) on 8 or 6 wires / CZ rings / RZ encoding / <Z>, with every RY in tangent form (one fused
+ * cross-lane multiply-add per gate).  post_mode 0 ("data" goal, x <- net(x)): linear_down is composed with linear_up
+ * into an n x n map of the previous step's <Z> (W_down is only read for the first step, and not at all when the circuit
+ * has one block per round: the data angles are then a global phase).  post_mode 1 ("noise" goal): the clamp breaks that
+ * composition; the image and both linears' weights stay in registers across the steps.  Tables: qiddm_dense_sample_lean_tables_bytes(circ) bytes, written once per
  * weights by _prepare (angles AND the two linears); _check synchronises the stream and returns 1 when the tables are
  * usable -- max |tan(theta/2)| <= 16 over the simulated layers -- 0 when the caller must use qiddm_dense_sample, < 0
  * on error.  Results agree with qiddm_dense_sample to rounding (not bit for bit).                                  */
@@ -268,8 +269,8 @@ int qiddm_dense_sample_lean_prepare(const qiddm_circuit_t *circ, const double *a
 int qiddm_dense_sample_lean_check(const qiddm_circuit_t *circ, const void *tables, void *stream);
 int qiddm_dense_sample_lean(const qiddm_circuit_t *circ, const double *x, int64_t batch, int64_t x_ld,
                             int64_t features, const double *w_down, const double *b_down, const double *w_up,
-                            const double *b_up, int32_t n_steps, double *y, int64_t y_ld, int64_t y_step_stride,
-                            const void *tables, void *stream);
+                            const double *b_up, int32_t post_mode, double noise_factor, int32_t n_steps, double *y,
+                            int64_t y_ld, int64_t y_step_stride, const void *tables, void *stream);
 
 /* ---- fused quantum convolution -------------------------------------------------------
  * Replaces the (intended, SURVEY finding F3) forward of the reference's exported QConv2d

@@ -156,7 +156,8 @@ def _declare(lib):
     lib.qiddm_dense_sample_lean_check.restype = ctypes.c_int
     lib.qiddm_dense_sample_lean_check.argtypes = [P, vp, vp]
     lib.qiddm_dense_sample_lean.restype = ctypes.c_int
-    lib.qiddm_dense_sample_lean.argtypes = [P, vp, i64, i64, i64, vp, vp, vp, vp, ctypes.c_int32, vp, i64, i64, vp, vp]
+    lib.qiddm_dense_sample_lean.argtypes = [P, vp, i64, i64, i64, vp, vp, vp, vp, ctypes.c_int32, ctypes.c_double,
+                                            ctypes.c_int32, vp, i64, i64, vp, vp]
     lib.qiddm_adjoint_partials.restype = i64
     lib.qiddm_adjoint_partials.argtypes = [P, i64]
     lib.qiddm_backward_adjoint.restype = ctypes.c_int

@@ -375,9 +375,9 @@ def dense_sample_lean_tables(circ: Circuit, angles, w_down, b_down, w_up, b_up, 
 
 
 def dense_sample_lean(circ: Circuit, x: torch.Tensor, w_down, b_down, w_up, b_up, n_steps: int, tables: torch.Tensor,
-                      precision: str | None = None):
-    """``n_steps`` bodies of the sampling loop for goal "data" in ONE launch of the lean kernel
-    (``qiddm_dense_sample_lean``).  Returns (n_steps, batch, features) float64."""
+                      precision: str | None = None, post_mode: int = 0, noise_factor: float = 1.0):
+    """``n_steps`` bodies of the sampling loop in ONE launch of the lean kernel (``qiddm_dense_sample_lean``;
+    ``post_mode`` / ``noise_factor`` as for ``dense_sample``).  Returns (n_steps, batch, features) float64."""
     precision = precision or _default_precision
     _require_device(x, "the input batch")
     device = tables.device
@@ -387,8 +387,9 @@ def dense_sample_lean(circ: Circuit, x: torch.Tensor, w_down, b_down, w_up, b_up
     cs = circ.c_struct(precision)
     _capi.check(_capi.lib().qiddm_dense_sample_lean(
         ctypes.byref(cs), xx.data_ptr(), xx.shape[0], xx.stride(0), xx.shape[1], wd.data_ptr(),
-        0 if bd is None else bd.data_ptr(), wu.data_ptr(), 0 if bu is None else bu.data_ptr(), int(n_steps),
-        y.data_ptr(), y.stride(1), y.stride(0), tables.data_ptr(), _stream_ptr(device)))
+        0 if bd is None else bd.data_ptr(), wu.data_ptr(), 0 if bu is None else bu.data_ptr(), int(post_mode),
+        float(noise_factor), int(n_steps), y.data_ptr(), y.stride(1), y.stride(0), tables.data_ptr(),
+        _stream_ptr(device)))
     return y
 
 

@@ -1,4 +1,4 @@
-// qiddm_quad8.hip -- C entry points of the lean sampling loop of the 8-qubit dense nets (qsim_lean.h):
+// qiddm_lean.hip -- C entry points of the lean sampling loop of the 8-qubit dense nets (qsim_lean.h):
 // qiddm_dense_sample_lean_tables_bytes / _prepare / _check / qiddm_dense_sample_lean (include/qiddm_hip.h).
 #include "capi_common.h"
 
@@ -55,11 +55,11 @@ qiddm::KScalars params_of(const qiddm_circuit_t* c) {
   return p;
 }
 
-template <typename T, int N, int PPT, bool REUP, int LPR>
+template <typename T, int N, int PPT, bool REUP, int LPR, bool POST>
 int launch_lean(const double* x, const double* wd, const double* bd, const double* wu, const double* bu, double* y,
                 const void* tables, const qiddm::QuadScalars& d, const qiddm::KScalars& p, int layers, hipStream_t st) {
   const size_t smem = qiddm::LeanTables<T, N>::lds_bytes(layers, p.n_rounds);
-  auto kern = qiddm::dense_lean_kernel<T, N, PPT, REUP, LPR>;
+  auto kern = qiddm::dense_lean_kernel<T, N, PPT, REUP, LPR, POST>;
   static qiddm_capi::DeviceFlags big_lds_enabled;
   if (smem > 48 * 1024 && !big_lds_enabled.get()) {
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -79,28 +79,31 @@ int launch_lean(const double* x, const double* wd, const double* bd, const doubl
 // drivers use (src/mnist_exm.py:46-48, src/fashion_exm.py:45) -- 8 qubits: 14 (QNN_noise(784, 8, 14)) and 12 (the
 // (8, 6, 2) LL / PL nets); 6 qubits: 28 (QIDDM_LL_noise(784, 6, 14, 2), the MNIST default) and 14 -- a runtime count
 // otherwise
-template <typename T, int N>
+template <typename T, int N, bool POST>
 int dispatch_lean_n(const double* x, const double* wd, const double* bd, const double* wu, const double* bu, double* y,
                     const void* tables, const qiddm::QuadScalars& d, const qiddm::KScalars& p, int layers, hipStream_t st) {
   const bool reup = p.n_blocks > 1;
   const int lpr = p.n_blocks * p.sel_layers;
   constexpr int kReupLpr = N == 8 ? 12 : 28;
   if (d.in_features > 1024)
-    return reup ? launch_lean<T, N, 8, true, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st)
-                : launch_lean<T, N, 8, false, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+    return reup ? launch_lean<T, N, 8, true, 0, POST>(x, wd, bd, wu, bu, y, tables, d, p, layers, st)
+                : launch_lean<T, N, 8, false, 0, POST>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
   if (reup) {
     if (lpr == kReupLpr && p.sel_layers == 2)
-      return launch_lean<T, N, 4, true, kReupLpr>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
-    return launch_lean<T, N, 4, true, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+      return launch_lean<T, N, 4, true, kReupLpr, POST>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+    return launch_lean<T, N, 4, true, 0, POST>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
   }
-  if (lpr == 14) return launch_lean<T, N, 4, false, 14>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
-  return launch_lean<T, N, 4, false, 0>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+  if (lpr == 14) return launch_lean<T, N, 4, false, 14, POST>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+  return launch_lean<T, N, 4, false, 0, POST>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
 }
 template <typename T>
 int dispatch_lean(int n, const double* x, const double* wd, const double* bd, const double* wu, const double* bu, double* y,
                   const void* tables, const qiddm::QuadScalars& d, const qiddm::KScalars& p, int layers, hipStream_t st) {
-  return n == 8 ? dispatch_lean_n<T, 8>(x, wd, bd, wu, bu, y, tables, d, p, layers, st)
-                : dispatch_lean_n<T, 6>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+  if (d.post_mode == 1)
+    return n == 8 ? dispatch_lean_n<T, 8, true>(x, wd, bd, wu, bu, y, tables, d, p, layers, st)
+                  : dispatch_lean_n<T, 6, true>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
+  return n == 8 ? dispatch_lean_n<T, 8, false>(x, wd, bd, wu, bu, y, tables, d, p, layers, st)
+                : dispatch_lean_n<T, 6, false>(x, wd, bd, wu, bu, y, tables, d, p, layers, st);
 }
 
 }  // namespace
@@ -157,13 +160,14 @@ int qiddm_dense_sample_lean_check(const qiddm_circuit_t* c, const void* tables, 
 
 int qiddm_dense_sample_lean(const qiddm_circuit_t* c, const double* x, int64_t batch, int64_t x_ld, int64_t features,
                             const double* w_down, const double* b_down, const double* w_up, const double* b_up,
-                            int32_t n_steps, double* y, int64_t y_ld, int64_t y_step_stride, const void* tables,
-                            void* stream) {
+                            int32_t post_mode, double noise_factor, int32_t n_steps, double* y, int64_t y_ld,
+                            int64_t y_step_stride, const void* tables, void* stream) {
   int rc = qiddm_capi::check_circuit(c);
   if (rc != QIDDM_OK) return rc;
   const int layers = lean_layers(c);
   if (layers < 0) return layers;
   if (batch < 0 || n_steps < 0) return fail(QIDDM_ERR_INVALID, "negative batch / n_steps");
+  if (post_mode != 0 && post_mode != 1) return fail(QIDDM_ERR_INVALID, "post_mode must be 0 or 1");
   if (features < 1 || features > 2048) return fail(QIDDM_ERR_UNSUPPORTED, "features=%lld outside 1..2048", (long long)features);
   if (batch == 0 || n_steps == 0) return QIDDM_OK;
   if (!x || !w_down || !w_up || !y || !tables) return fail(QIDDM_ERR_INVALID, "x/w_down/w_up/y/tables is NULL");
@@ -179,9 +183,9 @@ int qiddm_dense_sample_lean(const qiddm_circuit_t* c, const double* x, int64_t b
   d.y_step_stride = y_step_stride;
   d.in_features = (int32_t)features;
   d.out_features = (int32_t)features;
-  d.post_mode = 0;
+  d.post_mode = post_mode;
   d.n_steps = n_steps;
-  d.noise_factor = 1.0;
+  d.noise_factor = noise_factor;
   d.stamps = qiddm_capi::stamp_buffer(8);
   hipStream_t st = static_cast<hipStream_t>(stream);
   return c->dtype == QIDDM_F32

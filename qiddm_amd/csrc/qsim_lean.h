@@ -215,7 +215,10 @@ struct LeanLayer {
 // LPR:  layers per round as a compile-time constant (fully unrolled layer sequence; 14 = the flagship QNN_noise(784, 8,
 //       14), 12 / 28 = the LL-style (6 / 14 blocks x 2) -- with REUP a compiled-in count also means TWO layers per
 //       block), or 0 for a runtime count (loop over pairs of layers, block starts by comparison).
-template <typename T, int N, int PPT, bool REUP, int LPR>
+// POST: the "noise"-goal update of the sampling loop, x <- clamp(x - (net(x) - 0.5) * 0.1 * noise_factor, 0, 1)
+//       (reference src/models.py:130-134).  The clamp breaks the composite map, so the image stays in registers
+//       (PPT pixels per thread) and a re-uploading net runs its whole linear_down every step, weights in registers too.
+template <typename T, int N, int PPT, bool REUP, int LPR, bool POST>
 __global__ __launch_bounds__(256) void dense_lean_kernel(
     const double* __restrict__ x, const double* __restrict__ wd, const double* __restrict__ bd,
     const double* __restrict__ wu, const double* __restrict__ bu, double* __restrict__ y,
@@ -233,6 +236,7 @@ __global__ __launch_bounds__(256) void dense_lean_kernel(
   C* s_slab = reinterpret_cast<C*>(smem_raw + (QT::elems(layers, p.n_rounds) * sizeof(T) + 15) / 16 * 16);
   double* s_part = reinterpret_cast<double*>(s_slab + 2 * 4 * kWave);   // [4][16] partials of linear_down
   double* s_part_z = s_part + 4 * 16;                                    // [2][4][16] partials of the read-out, alternating
+  double* s_part2 = s_part_z + 4 * 4 * 16;                               // second buffer of linear_down's partials
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int llane = logical_lane(lane);
   double* s_xs = s_part_z + 2 * 4 * 16 + wv * 16;   // [16] angles of the round, this wave's copy
@@ -251,6 +255,17 @@ __global__ __launch_bounds__(256) void dense_lean_kernel(
 #pragma unroll
     for (int j = 0; j < N; ++j) wur[i][j] = pix < Q ? wu[(size_t)pix * N + j] : 0.0;   // (zeros beyond the image)
     bur[i] = (bu && pix < Q) ? bu[pix] : 0.0;
+  }
+  // "noise" goal: the image, and for a re-uploading net linear_down's weights and bias, live in registers
+  double xr[POST ? PPT : 1], wdr[POST && REUP ? PPT : 1][N], bdr = 0.0;
+  if constexpr (POST && REUP) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int pix = tid + i * 256;
+#pragma unroll
+      for (int j = 0; j < N; ++j) wdr[i][j] = pix < P ? wd[(size_t)j * P + pix] : 0.0;
+    }
+    bdr = (bd && lane < N) ? bd[lane] : 0.0;
   }
   {
     // 16 bytes per thread and trip, four trips in flight (the element count is a multiple of four)
@@ -302,7 +317,7 @@ __global__ __launch_bounds__(256) void dense_lean_kernel(
   __syncthreads();
   if (stamp) d.stamps[1] = __builtin_amdgcn_s_memtime();
 
-  int xbuf_parity = 0, zbuf_parity = 0;
+  int xbuf_parity = 0, zbuf_parity = 0, dbuf_parity = 0;
   double ev[8];   // <Z_w> of the last round (N used): linear_up's input and the next step's composite input
 #pragma unroll
   for (int j = 0; j < 8; ++j) ev[j] = 0.0;
@@ -312,24 +327,45 @@ __global__ __launch_bounds__(256) void dense_lean_kernel(
       const bool st = stamp && step == 1;
       if (st) d.stamps[2] = __builtin_amdgcn_s_memtime();
       // ---- this step's data angles -------------------------------------------------------------------------
-      if constexpr (REUP) {
+      if constexpr (POST) {
         if (step == 0) {
-          // linear_down on the input image (the only step that reads an image)
+#pragma unroll
+          for (int i = 0; i < PPT; ++i) {
+            const int pix = tid + i * 256;
+            xr[i] = pix < P ? x[sample * d.x_ld + pix] : 0.0;
+          }
+        }
+      }
+      if constexpr (REUP) {
+        if (POST || step == 0) {
+          // linear_down on the image: the launch's input, or ("noise" goal) the registers' current image every step.
+          // (two partial buffers in turn: with six qubits no barrier separates one step's readers from the next one's
+          //  writers)
+          double* part = dbuf_parity ? s_part2 : s_part;
+          dbuf_parity ^= 1;
           double acc[8];
 #pragma unroll
           for (int j = 0; j < 8; ++j) acc[j] = 0.0;
-#pragma unroll 1
-          for (int i = 0; i < PPT; ++i) {     // (pixel by pixel: once per launch and sample, keep its registers few)
-            const int pix = tid + i * 256;
-            const double xv = pix < P ? x[sample * d.x_ld + pix] : 0.0;
+          if constexpr (POST) {
 #pragma unroll
-            for (int j = 0; j < N; ++j) acc[j] = fma(xv, pix < P ? wd[(size_t)j * P + pix] : 0.0, acc[j]);
+            for (int i = 0; i < PPT; ++i) {
+#pragma unroll
+              for (int j = 0; j < N; ++j) acc[j] = fma(xr[i], wdr[i][j], acc[j]);
+            }
+          } else {
+#pragma unroll 1
+            for (int i = 0; i < PPT; ++i) {     // (pixel by pixel: once per launch and sample, keep its registers few)
+              const int pix = tid + i * 256;
+              const double xv = pix < P ? x[sample * d.x_ld + pix] : 0.0;
+#pragma unroll
+              for (int j = 0; j < N; ++j) acc[j] = fma(xv, pix < P ? wd[(size_t)j * P + pix] : 0.0, acc[j]);
+            }
           }
-          wave_reduce8_into<double, true>(acc, lane, llane, s_part + wv * 16);
+          wave_reduce8_into<double, true>(acc, lane, llane, part + wv * 16);
           __syncthreads();
           if (lane < N) {
-            const double h = s_part[lane] + s_part[16 + lane] + s_part[32 + lane] + s_part[48 + lane] +
-                             (bd ? bd[lane] : 0.0);
+            const double h = part[lane] + part[16 + lane] + part[32 + lane] + part[48 + lane] +
+                             (POST ? bdr : (bd ? bd[lane] : 0.0));
             s_xs[lane] = h * p.enc_scale;
           }
         } else {
@@ -546,6 +582,10 @@ __global__ __launch_bounds__(256) void dense_lean_kernel(
 #pragma unroll
       for (int i = 0; i < PPT; ++i) {
         o0[i] += o1[i];
+        if constexpr (POST) {
+          o0[i] = fmin(fmax(xr[i] - (o0[i] - 0.5) * 0.1 * d.noise_factor, 0.0), 1.0);
+          xr[i] = o0[i];
+        }
         asm volatile("" : "+v"(o0[i]));   // (keeps the sums out of the stores' predicated blocks: all of them advance together)
       }
 #pragma unroll

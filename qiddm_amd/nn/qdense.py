@@ -98,7 +98,7 @@ class _QuantumNet(nn.Module):
         return cached[1], cached[2]
 
     def _lean_sampler_tables(self, circ, angles, lin_down, lin_up):
-        """Tables of the lean 8- / 6-qubit sampler (goal "data"), rebuilt only when the weights, the two linears or the
+        """Tables of the lean 8- / 6-qubit sampler, rebuilt only when the weights, the two linears or the
         precision changed; None when that kernel does not apply (then the general sampler runs)."""
         tensors = (angles, lin_down.weight, lin_down.bias, lin_up.weight, lin_up.bias)
         stamp = tuple((t._version, t.data_ptr()) for t in tensors if t is not None) + \
@@ -113,15 +113,16 @@ class _QuantumNet(nn.Module):
         return cached[1]
 
     def _fused_sampler_launch(self, circ, flat, angles, n_steps, goal, noise_factor):
-        """n_steps loop bodies in one launch: the lean 8- / 6-qubit kernel where it applies (goal "data"), else the general
+        """n_steps loop bodies in one launch: the lean 8- / 6-qubit kernel where it applies, else the general
         four-wavefront sampler."""
         ld, lu = self.linear_down, self.linear_up
-        if goal == "data":
-            lean = self._lean_sampler_tables(circ, angles, ld, lu)
-            if lean is not None:
-                return _c.dense_sample_lean(circ, flat, ld.weight, ld.bias, lu.weight, lu.bias, n_steps, lean)
+        post_mode = 0 if goal == "data" else 1
+        lean = self._lean_sampler_tables(circ, angles, ld, lu)
+        if lean is not None:
+            return _c.dense_sample_lean(circ, flat, ld.weight, ld.bias, lu.weight, lu.bias, n_steps, lean,
+                                        post_mode=post_mode, noise_factor=noise_factor)
         return _c.dense_sample(circ, flat, ld.weight, ld.bias, angles.reshape(circ.angles_shape), lu.weight, lu.bias,
-                               n_steps, post_mode=0 if goal == "data" else 1, noise_factor=noise_factor,
+                               n_steps, post_mode=post_mode, noise_factor=noise_factor,
                                tables=self._sampler_tables(circ, angles))
 
     # -- fused training step (SURVEY.md section 8f rank 1) -------------------------------------------------

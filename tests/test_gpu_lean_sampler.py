@@ -61,6 +61,44 @@ def test_lean_sampler_matches_oracle(n, N, L, S, P, precision, tol):
     assert torch.allclose(got, gen, atol=tol, rtol=tol), (got - gen).abs().max()
 
 
+def _oracle_noise_steps(x, wd, bd, wu, bu, w, steps, nf):
+    """The "noise"-goal loop body (reference src/models.py:130-134) around the oracle's net."""
+    spec = oc.Spec(n=w.shape[-2], encoding="rz", imprimitive="CZ", measure="expz")
+    cur, refs = x, []
+    for _ in range(steps):
+        net = oc.run_circuit(spec, cur @ wd.T + bd, w) @ wu.T + bu
+        cur = torch.clamp(cur - (net - 0.5) * 0.1 * nf, 0, 1)
+        refs.append(cur)
+    return torch.stack(refs)
+
+
+@pytest.mark.parametrize("precision,tol", [("f32", 5e-5), ("f64", 1e-10)])
+@pytest.mark.parametrize("n,N,L,S,P", [
+    (8, 1, 1, 14, 784), (8, 2, 6, 2, 784), (8, 1, 3, 3, 300), (8, 2, 1, 1, 64), (8, 1, 2, 1, 1500), (8, 3, 2, 2, 100),
+    (6, 2, 14, 2, 784), (6, 1, 1, 14, 784), (6, 2, 3, 3, 300), (6, 3, 1, 1, 64), (6, 1, 2, 2, 1500)])
+def test_lean_sampler_noise_goal_matches_oracle(n, N, L, S, P, precision, tol):
+    """post_mode 1: x <- clamp(x - (net(x) - 0.5) * 0.1 * noise_factor, 0, 1), the image carried in registers; the update
+    moves the image by a tenth of the net's output per step, hence the tighter float32 bound.  Six steps, so that a
+    six-qubit net's alternating partial-sum buffers are each reused."""
+    from qiddm_amd.circuit import Circuit, dense_sample, dense_sample_lean, dense_sample_lean_tables
+    x, wd, bd, wu, bu, w = _case(N, L, S, P, seed=100 * N + 10 * L + S + n + 1, n=n)
+    x = x * 1.2 - 0.1                                   # some pixels start outside [0, 1]; the clamp acts from step 1 on
+    circ = Circuit(n_qubits=n, encoding="rz", imprimitive="CZ", measure="expz", n_rounds=N, n_blocks=L, sel_layers=S)
+    dev = lambda t: t.to(DEV)
+    tables = dense_sample_lean_tables(circ, dev(w), dev(wd), dev(bd), dev(wu), dev(bu), precision)
+    assert tables is not None
+    steps, nf = 6, 1.7
+    got = dense_sample_lean(circ, dev(x), dev(wd), dev(bd), dev(wu), dev(bu), steps, tables, precision,
+                            post_mode=1, noise_factor=nf).cpu()
+    ref = _oracle_noise_steps(x, wd, bd, wu, bu, w, steps, nf)
+    assert got.shape == ref.shape
+    assert float(ref.min()) == 0.0 and float(ref.max()) == 1.0, "the case must exercise both clamp bounds"
+    assert torch.allclose(got, ref, atol=tol, rtol=0), (got - ref).abs().max()
+    gen = dense_sample(circ, dev(x), dev(wd), dev(bd), dev(w), dev(wu), dev(bu), steps, precision,
+                       post_mode=1, noise_factor=nf).cpu()
+    assert torch.allclose(got, gen, atol=tol, rtol=0), (got - gen).abs().max()
+
+
 def test_lean_sampler_many_samples_and_strided_input():
     """More samples than workgroups in flight (grid-stride loop over samples) and an input with a row stride."""
     from qiddm_amd.circuit import Circuit, dense_sample_lean, dense_sample_lean_tables
@@ -145,3 +183,25 @@ def test_nets_route_goal_data_through_the_lean_kernel_and_track_weight_updates(c
         g.replay()
         torch.cuda.synchronize()
         assert torch.equal(rec, got2)
+
+
+@pytest.mark.parametrize("ctor", [lambda nn: nn.QNN_noise(784, 8, 14), lambda nn: nn.QIDDM_LL_noise(784, 8, 6, 2),
+                                  lambda nn: nn.QIDDM_LL_noise(784, 6, 14, 2)])
+def test_nets_route_goal_noise_through_the_lean_kernel(ctor, monkeypatch):
+    """Diffusion(..., "noise").denoise_steps: the same lean kernel with the clamp update; the general sampler must not run."""
+    from qiddm_amd import circuit, models, nn, noise
+    torch.manual_seed(22)
+    net = ctor(nn)
+    diff = models.Diffusion(net, noise.add_normal_noise_multiple, "noise", (28, 28)).to(DEV, dtype=torch.double).eval()
+    x = (torch.rand(5, 1, 28, 28, dtype=torch.float64) * 0.75 + 0.5).to(DEV)
+
+    def refuse(*a, **k):
+        raise AssertionError("the general sampler ran")
+    monkeypatch.setattr(circuit, "dense_sample", refuse)
+    with torch.no_grad():
+        got = diff.denoise_steps(x, 4, noise_factor=0.8).cpu()
+    sd = {k[4:]: v.detach().cpu() for k, v in diff.state_dict().items()}
+    w = sd["weights1"] if "weights1" in sd else sd["weights"].reshape((1, 1) + tuple(sd["weights"].shape))
+    ref = _oracle_noise_steps(x.cpu().reshape(5, 784), sd["linear_down.weight"], sd["linear_down.bias"],
+                              sd["linear_up.weight"], sd["linear_up.bias"], w, 4, 0.8).reshape(4, 5, 1, 28, 28)
+    assert torch.allclose(got, ref, atol=5e-5, rtol=0), (got - ref).abs().max()

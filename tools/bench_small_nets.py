@@ -1,6 +1,6 @@
 """Denoise-step rate of the reference's shipped dense configurations (src/mnist_exm.py:45-49, src/fashion_exm.py:45) at
 batch 256, f32 and f64, through bench.py's own Runner (15 steps per launch, hipGraph replay).
-A/B of the lean 8-qubit sampler:  QIDDM_NO_LEAN_SAMPLER=1 python tools/bench_small_nets.py"""
+A/B of the lean sampler:  QIDDM_NO_LEAN_SAMPLER=1 python tools/bench_small_nets.py ;  the "noise" goal:  QIDDM_GOAL=noise ..."""
 import os
 import sys
 
@@ -11,9 +11,10 @@ import bench  # noqa: E402
 import qiddm_amd  # noqa: E402
 from qiddm_amd import models, nn, noise  # noqa: E402
 
+GOAL = os.environ.get("QIDDM_GOAL", "data")
 dev = torch.device("cuda:0")
 x = (torch.rand(256, 1, 28, 28, dtype=torch.double) * 0.75 + 0.5).to(dev)
-print("lean sampler:", "off" if os.environ.get("QIDDM_NO_LEAN_SAMPLER") == "1" else "on")
+print("goal:", GOAL, " lean sampler:", "off" if os.environ.get("QIDDM_NO_LEAN_SAMPLER") == "1" else "on")
 for prec in ("f32", "f64"):
     qiddm_amd.set_default_precision(prec)
     for name, ctor in (("QNN_noise(784,8,14)", lambda: nn.QNN_noise(784, 8, 14)),
@@ -23,7 +24,7 @@ for prec in ("f32", "f64"):
                        ("QNN_noise(784,10,6)", lambda: nn.QNN_noise(784, 10, 6))):
         torch.manual_seed(42)
         net = ctor().to(dev, dtype=torch.double).eval()
-        diff = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (28, 28)).to(dev, dtype=torch.double).eval()
+        diff = models.Diffusion(net, noise.add_normal_noise_multiple, GOAL, (28, 28)).to(dev, dtype=torch.double).eval()
         try:
             r = bench.Runner(diff, x, True, 15)
             r.prepare(75)
