@@ -100,7 +100,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec, /opt/skills/guides/MI355X_MI
 VALU_PEAK_TF = 157.3           # f32 vector peak (= the f32 MFMA peak), same guide
 N_QUBITS, QDEPTH, IMG = 8, 14, 28
 MIN_TIMED_S = 0.05
-HEADLINE_KERNEL = "qiddm::dense_lean_kernel<{}, 8, 4, false, 14>"
+HEADLINE_KERNEL = "qiddm::dense_lean_kernel<{}, 8, 4, false, 14, false>"
 TRAFFIC_PROFILE = "profiles/r03b/bench_pmc_traffic.json"     # FETCH_SIZE / WRITE_SIZE passes of the driver's command
 HEADLINE_NOTE = ("latency-bound at batch 256: one sample per CU, one wavefront per SIMD, and a layer is ONE dependent chain "
                  "(every gate acts on the same 256 amplitudes): ~11 cycles per dependent vector instruction for a lone "
@@ -451,20 +451,24 @@ def secondary_dense_samplers(dev, out):
     """The other dense nets of the path through the same fused sampling loop (reference drivers' own parameter lists),
     each with a small roofline block for its launch (15 steps per launch; HIP events)."""
     from qiddm_amd import models, nn, noise
+    down = 2 * IMG * IMG * 8          # the "noise" goal runs the whole linear_down every step (no composite map)
     cases = (
-        # tag, ctor, batch, image side, gates/sample, n, layers per round, rounds, kernel, executed flop per sample-step
+        # tag, ctor, batch, image side, gates/sample, kernel, executed flop per sample-step, prediction goal
         ("QIDDM_LL_noise(784,8,6,2)", lambda: nn.QIDDM_LL_noise(IMG * IMG, 8, 6, 2), 256, IMG, 480,          # src/fashion_exm.py:45 (LL form)
-         "qiddm::dense_lean_kernel<float, 8, 4, true, 12>", lean_flop(8, 12, 2, IMG * IMG, True)),
+         "qiddm::dense_lean_kernel<float, 8, 4, true, 12, false>", lean_flop(8, 12, 2, IMG * IMG, True), "data"),
         ("QIDDM_LL_noise(784,6,14,2)", lambda: nn.QIDDM_LL_noise(IMG * IMG, 6, 14, 2), 256, IMG, 840,        # src/mnist_exm.py:46
-         "qiddm::dense_lean_kernel<float, 6, 4, true, 28>", lean_flop(6, 28, 2, IMG * IMG, True)),
+         "qiddm::dense_lean_kernel<float, 6, 4, true, 28, false>", lean_flop(6, 28, 2, IMG * IMG, True), "data"),
+        ("QIDDM_LL_noise(784,8,6,2)_goal_noise", lambda: nn.QIDDM_LL_noise(IMG * IMG, 8, 6, 2), 256, IMG, 480,
+         "qiddm::dense_lean_kernel<float, 8, 4, true, 12, true>", lean_flop(8, 12, 2, IMG * IMG, True) - 128 + down,
+         "noise"),                                                                                          # src/models.py:130-134
         ("C1_QNN_noise(64,4,2)_b32", lambda: nn.QNN_noise(64, 4, 2), 32, 8, 20,                              # src/mnist_noise.py:49
-         "qiddm::dense_quad_kernel<float, 4, 4>", dense_flop(4, 2, 1, 64)),
+         "qiddm::dense_quad_kernel<float, 4, 4>", dense_flop(4, 2, 1, 64), "data"),
     )
-    for tag, ctor, batch, side, gates, kernel, flop in cases:
+    for tag, ctor, batch, side, gates, kernel, flop, goal in cases:
         try:
             torch.manual_seed(42)
             net = ctor().to(dev, dtype=torch.double).eval()
-            d = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (side, side)).to(dev, dtype=torch.double).eval()
+            d = models.Diffusion(net, noise.add_normal_noise_multiple, goal, (side, side)).to(dev, dtype=torch.double).eval()
             x = (torch.rand(batch, 1, side, side, dtype=torch.double) * 0.75 + 0.5).to(dev)
             r = Runner(d, x, True, 15)
             r.prepare(75)
