@@ -472,6 +472,20 @@ int qiddm_qconv_train_backward_x32(int32_t n_qubits, const float *x, int64_t bat
                                    const double *grad_y, int64_t out_channels, const float *rows,
                                    int32_t row_channels, float *grad_features_t, float *h_partials, double *grad_x,
                                    void *stream);
+/* dL/dx without the feature-gradient matrix (qsim_qconv_dx.h): the fold commutes with the second product, so the thin-
+ * product kernel only leaves 2 row_channels + 1 floats per output pixel (`pixel_rows`: qiddm_qconv_train_dx_elems()
+ * floats) and a second kernel makes grad_x from them as a transposed convolution on the matrix cores -- C kh kw / (2
+ * row_channels + 1) times less memory traffic than grad_features_t + fold.  Same-size convolutions (Ho = H, Wo = W) on the
+ * matrix-core kernel with at most 32 input channels: qiddm_qconv_train_dx_elems() returns 0 for anything else, and
+ * qiddm_qconv_train_backward_dx then QIDDM_ERR_UNSUPPORTED (use qiddm_qconv_train_backward).  Same h_partials; grad_x
+ * agrees with the fold route to float32 rounding (the nine taps are summed in float32 instead of float64).         */
+int64_t qiddm_qconv_train_dx_elems(int32_t n_qubits, int64_t batch, int64_t in_channels, int64_t height, int64_t width,
+                                   int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, int64_t out_channels,
+                                   int32_t row_channels);
+int qiddm_qconv_train_backward_dx(int32_t n_qubits, const double *x, int64_t batch, int64_t in_channels,
+                                  int64_t height, int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
+                                  const double *grad_y, int64_t out_channels, const float *rows, int32_t row_channels,
+                                  float *pixel_rows, float *h_partials, double *grad_x, void *stream);
 int64_t qiddm_matrix_adjoint_partials(int64_t count);
 int64_t qiddm_matrix_adjoint_workspace_bytes(const qiddm_circuit_t *circ, int64_t count);
 int qiddm_matrix_adjoint(const qiddm_circuit_t *circ, const double *psi0, const double *lambda, int64_t count,

@@ -70,6 +70,8 @@ EXPORTS = (
     "qiddm_qconv_train_backward",
     "qiddm_qconv_train_x32_ok",
     "qiddm_qconv_train_backward_x32",
+    "qiddm_qconv_train_dx_elems",
+    "qiddm_qconv_train_backward_dx",
     "qiddm_matrix_adjoint_partials",
     "qiddm_matrix_adjoint_workspace_bytes",
     "qiddm_matrix_adjoint",
@@ -192,6 +194,11 @@ def _declare(lib):
     lib.qiddm_qconv_train_x32_ok.argtypes = [i64, i64, i64, i64, i64, i64, i64, i64, i64, ctypes.c_int32]
     lib.qiddm_qconv_train_backward_x32.restype = ctypes.c_int
     lib.qiddm_qconv_train_backward_x32.argtypes = lib.qiddm_qconv_train_backward.argtypes
+    lib.qiddm_qconv_train_dx_elems.restype = ctypes.c_int64
+    lib.qiddm_qconv_train_dx_elems.argtypes = [ctypes.c_int32, i64, i64, i64, i64, i64, i64, i64, i64, i64, ctypes.c_int32]
+    lib.qiddm_qconv_train_backward_dx.restype = ctypes.c_int
+    lib.qiddm_qconv_train_backward_dx.argtypes = [ctypes.c_int32, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, vp,
+                                                  ctypes.c_int32, vp, vp, vp, vp]
     lib.qiddm_matrix_adjoint_partials.restype = ctypes.c_int64
     lib.qiddm_matrix_adjoint_partials.argtypes = [i64]
     lib.qiddm_matrix_adjoint_workspace_bytes.restype = ctypes.c_int64

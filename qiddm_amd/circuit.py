@@ -704,6 +704,55 @@ def qconv_unitary_trainable(n_qubits: int, in_channels: int, kernel_size, out_ch
     return qconv_unitary_route(n_qubits, in_channels, kernel_size, out_channels) is not None
 
 
+# The weight-gradient chain of a quantum convolution (start vectors, gate table, one adjoint sweep per output channel,
+# finalize, then the pi * tanh backward of the weights: ~90 us of small launches per layer) hangs off the layer's
+# backward but nothing downstream of the layer needs it before the optimizer step.  It runs on a side stream:
+# the ANGLES are computed on that stream in the forward, so autograd schedules their backward nodes there by itself
+# (a backward node runs on its forward's stream; the engine joins the leaf streams when backward() returns), and the
+# Function's backward enqueues the chain there after the thin-product kernel.  Inside a HIP-graph recording the fork
+# becomes a parallel branch of the graph.  QIDDM_NO_WEIGHT_GRAD_STREAM=1 keeps everything on one stream.
+_WEIGHT_GRAD_STREAM = os.environ.get("QIDDM_NO_WEIGHT_GRAD_STREAM", "0") != "1"
+_weight_grad_streams = {}
+
+
+def weight_grad_stream(device):
+    """The side stream of ``device`` for the convolutions' weight-gradient chains; None when switched off."""
+    if not _WEIGHT_GRAD_STREAM or device.type != "cuda":
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    side = _weight_grad_streams.get(idx)
+    if side is None:
+        side = _weight_grad_streams[idx] = torch.cuda.Stream(device=idx)
+    return None if torch.cuda.current_stream(idx) == side else side
+
+
+def on_weight_grad_stream(fn, weights: torch.Tensor) -> torch.Tensor:
+    """``fn(weights)`` (the layer's angle map) enqueued on the weight-gradient stream when autograd is recording, so
+    that its backward nodes run there; the current stream waits for the result."""
+    side = weight_grad_stream(weights.device) if torch.is_grad_enabled() and weights.requires_grad else None
+    if side is None:
+        return fn(weights)
+    main = torch.cuda.current_stream(weights.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        out = fn(weights)
+    main.wait_stream(side)
+    out.record_stream(main)
+    return out
+
+
+def _angle_grads_off_stream(hpart, n_part, angles, n_qubits, f, c_out, co, device):
+    """``_angle_grads_from_h`` behind everything the current stream has enqueued, on the weight-gradient stream."""
+    side = weight_grad_stream(device)
+    if side is None:
+        return _angle_grads_from_h(hpart, n_part, angles, n_qubits, f, c_out, co, device).to(angles.dtype)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        ga = _angle_grads_from_h(hpart, n_part, angles, n_qubits, f, c_out, co, device).to(angles.dtype)
+    hpart.record_stream(side)
+    return ga
+
+
 def _unitary_rows(u, n_qubits, f, c_out, co, device):
     """(F + 1, 2 co) float32 rows table of the backward (``qiddm_qconv_train_rows``)."""
     transposed = (not u.is_contiguous()) and u.transpose(0, 1).is_contiguous()
@@ -745,6 +794,9 @@ def _angle_grads_from_h(hpart, n_part, angles, n_qubits, f, c_out, co, device):
 # Measured at the unet_simple layer shapes (tools/stamp_qconv_train.py) the copy pass costs what the lighter gather gains
 # (1.35 vs 1.26 ms, 0.95 vs 0.93 ms, 0.34 vs 0.36 ms per layer backward), so float64 activations go in as they are
 _QCONV_X32 = os.environ.get("QIDDM_QCONV_X32", "0") == "1"
+# QIDDM_QCONV_FOLD=1: keep the (F, M) feature gradients + fold for dL/dx instead of the per-pixel rows + transposed
+# convolution (qiddm_qconv_train_backward_dx); the library reads the same variable
+_QCONV_DX = os.environ.get("QIDDM_QCONV_FOLD") is None
 _GEMM_CHUNK_BYTES = 256 << 20      # patch matrix of one batch chunk on the "gemm" route
 
 
@@ -812,8 +864,9 @@ class _QConvUnitaryFunction(torch.autograd.Function):
         need_gx = ctx.needs_input_grad[0]
         if qconv_unitary_route(n_qubits, c, (kh, kw), c_out) == "gemm":
             hpart, gx = _qconv_unitary_backward_gemm(x, grad_y, u, n_qubits, c_out, (kh, kw), (ph, pw), need_gx)
-            ga = _angle_grads_from_h(hpart, 1, angles, n_qubits, f, c_out, c_out, device)
-            return (None if gx is None else gx.to(x.dtype)), ga.to(angles.dtype), None, None, None, None
+            ga = _angle_grads_off_stream(hpart, 1, angles, n_qubits, f, c_out, c_out, device) \
+                if ctx.needs_input_grad[1] else None
+            return (None if gx is None else gx.to(x.dtype)), ga, None, None, None, None
         co = _row_channels(c_out)
         lib = _capi.lib()
         st = _stream_ptr(device)
@@ -824,14 +877,25 @@ class _QConvUnitaryFunction(torch.autograd.Function):
         xx = x.detach().to(device=device, dtype=torch.float32).contiguous() if x32 else _as_f64(x, device).contiguous()
         gy = _as_f64(grad_y, device).contiguous()
         n_part = lib.qiddm_qconv_train_partials(b, ho, wo, f)
-        gfeat_t = torch.empty(f, b * ho * wo, dtype=torch.float32, device=device)
         hpart = torch.empty(n_part, 2 * co, f + 1, dtype=torch.float32, device=device)
         gx = torch.empty(b, c, h, w, dtype=torch.float64, device=device) if need_gx else None
-        entry = lib.qiddm_qconv_train_backward_x32 if x32 else lib.qiddm_qconv_train_backward
-        _capi.check(entry(n_qubits, xx.data_ptr(), b, c, h, w, kh, kw, ph, pw, gy.data_ptr(), c_out, rt.data_ptr(), co,
-                          gfeat_t.data_ptr(), hpart.data_ptr(), 0 if gx is None else gx.data_ptr(), st))
-        ga = _angle_grads_from_h(hpart, n_part, angles, n_qubits, f, c_out, co, device)
-        return (None if gx is None else gx.to(x.dtype)), ga.to(angles.dtype), None, None, None, None
+        # dL/dx from 2 co + 1 floats per pixel where the layer allows it (same-size convolution on the matrix-core
+        # kernel), instead of the (F, M) feature gradients and their fold
+        dx_elems = 0 if (gx is None or x32 or not _QCONV_DX) else lib.qiddm_qconv_train_dx_elems(n_qubits, b, c, h, w, kh, kw, ph, pw,
+                                                                                c_out, co)
+        if dx_elems > 0:
+            wpix = torch.empty(dx_elems, dtype=torch.float32, device=device)
+            _capi.check(lib.qiddm_qconv_train_backward_dx(n_qubits, xx.data_ptr(), b, c, h, w, kh, kw, ph, pw,
+                                                          gy.data_ptr(), c_out, rt.data_ptr(), co, wpix.data_ptr(),
+                                                          hpart.data_ptr(), gx.data_ptr(), st))
+        else:
+            gfeat_t = torch.empty(f, b * ho * wo, dtype=torch.float32, device=device)
+            entry = lib.qiddm_qconv_train_backward_x32 if x32 else lib.qiddm_qconv_train_backward
+            _capi.check(entry(n_qubits, xx.data_ptr(), b, c, h, w, kh, kw, ph, pw, gy.data_ptr(), c_out, rt.data_ptr(),
+                              co, gfeat_t.data_ptr(), hpart.data_ptr(), 0 if gx is None else gx.data_ptr(), st))
+        ga = _angle_grads_off_stream(hpart, n_part, angles, n_qubits, f, c_out, co, device) \
+            if ctx.needs_input_grad[1] else None
+        return (None if gx is None else gx.to(x.dtype)), ga, None, None, None, None
 
 
 def qconv_unitary_execute(x: torch.Tensor, angles: torch.Tensor, n_qubits: int, out_channels: int, kernel_size,

@@ -4,9 +4,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
+#include "qsim_qconv_dx.h"
 #include "qsim_qconv_train.h"
 #include "qsim_qconv_train_mfma.h"
 #include "qsim_unitary.h"
@@ -316,9 +318,88 @@ bool train_fits32(int64_t batch, int64_t in_channels, int64_t height, int64_t wi
 int train_backward(int32_t n_qubits, const void* x, bool x32, int64_t batch, int64_t in_channels, int64_t height,
                    int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, const double* grad_y,
                    int64_t out_channels, const float* rows, int32_t row_channels, float* grad_features_t,
-                   float* h_partials, double* grad_x, void* stream);
+                   float* pixel_rows, float* h_partials, double* grad_x, void* stream);
+
+// dL/dx from per-pixel rows (qsim_qconv_dx.h) instead of feature gradients + fold: the matrix-core kernel, a same-size
+// convolution, at most 32 input channels, LDS of the dx kernel within the limit.  QIDDM_QCONV_FOLD=1 switches it off.
+struct DxChoice {
+  const void* kern = nullptr;
+  size_t smem = 0;
+};
+DxChoice train_dx_choice(const qiddm::TrainConv& tc, int32_t row_channels, bool mfma) {
+  static const bool env_fold = std::getenv("QIDDM_QCONV_FOLD") != nullptr;
+  DxChoice ch;
+  if (env_fold || !mfma || tc.Ho != tc.H || tc.Wo != tc.W || tc.C > 32 || tc.kh * tc.kw > 32) return ch;
+  size_t smem = 0;
+  const void* kern = nullptr;
+  if (row_channels == 8) {
+    smem = qiddm::dx_lds_bytes<16>(tc);
+    kern = reinterpret_cast<const void*>(qiddm::qconv_dx_kernel<16>);
+  } else if (row_channels == 16) {
+    smem = qiddm::dx_lds_bytes<32>(tc);
+    kern = reinterpret_cast<const void*>(qiddm::qconv_dx_kernel<32>);
+  } else if (row_channels == 32) {
+    smem = qiddm::dx_lds_bytes<64>(tc);
+    kern = reinterpret_cast<const void*>(qiddm::qconv_dx_kernel<64>);
+  }
+  if (kern && smem <= kMaxLds / 2) {   // (two or more workgroups per CU)
+    ch.kern = kern;
+    ch.smem = smem;
+  }
+  return ch;
+}
+qiddm::TrainConv train_geometry(int32_t n_qubits, int64_t batch, int64_t in_channels, int64_t height, int64_t width,
+                                int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, int64_t out_channels) {
+  const int64_t d = (int64_t)1 << n_qubits, f = in_channels * kh * kw;
+  const int64_t ho = height + 2 * pad_h - kh + 1, wo = width + 2 * pad_w - kw + 1;
+  qiddm::TrainConv tc;
+  std::memset(&tc, 0, sizeof(tc));
+  tc.C = (int32_t)in_channels;
+  tc.H = (int32_t)height;
+  tc.W = (int32_t)width;
+  tc.kh = (int32_t)kh;
+  tc.kw = (int32_t)kw;
+  tc.ph = (int32_t)pad_h;
+  tc.pw = (int32_t)pad_w;
+  tc.Ho = (int32_t)ho;
+  tc.Wo = (int32_t)wo;
+  tc.C_out = (int32_t)out_channels;
+  tc.F = (int32_t)f;
+  tc.M = batch * ho * wo;
+  tc.pad_norm2 = 0.25f * (float)(d - f);
+  tc.post_scale = 0.5f * (float)d;
+  return tc;
+}
 }  // namespace
 }  // extern "C++"
+
+int64_t qiddm_qconv_train_dx_elems(int32_t n_qubits, int64_t batch, int64_t in_channels, int64_t height, int64_t width,
+                                   int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, int64_t out_channels,
+                                   int32_t row_channels) {
+  if (n_qubits < 1 || n_qubits > 12 || batch < 1 || in_channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 ||
+      pad_h < 0 || pad_w < 0 || out_channels < 1 || kh > 15 || kw > 15)
+    return 0;
+  const int64_t ho = height + 2 * pad_h - kh + 1, wo = width + 2 * pad_w - kw + 1;
+  if (ho < 1 || wo < 1) return 0;
+  const int64_t f = in_channels * kh * kw;
+  const qiddm::TrainConv tc = train_geometry(n_qubits, batch, in_channels, height, width, kh, kw, pad_h, pad_w, out_channels);
+  const bool mfma = train_mfma_choice(f, row_channels, train_fits32(batch, in_channels, height, width, out_channels, ho, wo),
+                                      false, kh, kw, in_channels).kern != nullptr;
+  if (!train_dx_choice(tc, row_channels, mfma).kern) return 0;
+  return tc.M * (2 * (int64_t)row_channels + 1);
+}
+
+int qiddm_qconv_train_backward_dx(int32_t n_qubits, const double* x, int64_t batch, int64_t in_channels, int64_t height,
+                                  int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
+                                  const double* grad_y, int64_t out_channels, const float* rows, int32_t row_channels,
+                                  float* pixel_rows, float* h_partials, double* grad_x, void* stream) {
+  if (!pixel_rows || !grad_x) return fail(QIDDM_ERR_INVALID, "pixel_rows/grad_x is NULL");
+  if (qiddm_qconv_train_dx_elems(n_qubits, batch, in_channels, height, width, kh, kw, pad_h, pad_w, out_channels,
+                                 row_channels) <= 0)
+    return fail(QIDDM_ERR_UNSUPPORTED, "this layer keeps the feature-gradient route (qiddm_qconv_train_dx_elems() == 0)");
+  return train_backward(n_qubits, x, false, batch, in_channels, height, width, kh, kw, pad_h, pad_w, grad_y,
+                        out_channels, rows, row_channels, nullptr, pixel_rows, h_partials, grad_x, stream);
+}
 
 int32_t qiddm_qconv_train_x32_ok(int64_t batch, int64_t in_channels, int64_t height, int64_t width, int64_t kh,
                                  int64_t kw, int64_t pad_h, int64_t pad_w, int64_t out_channels, int32_t row_channels) {
@@ -340,7 +421,7 @@ int qiddm_qconv_train_backward(int32_t n_qubits, const double* x, int64_t batch,
                                const double* grad_y, int64_t out_channels, const float* rows, int32_t row_channels,
                                float* grad_features_t, float* h_partials, double* grad_x, void* stream) {
   return train_backward(n_qubits, x, false, batch, in_channels, height, width, kh, kw, pad_h, pad_w, grad_y,
-                        out_channels, rows, row_channels, grad_features_t, h_partials, grad_x, stream);
+                        out_channels, rows, row_channels, grad_features_t, nullptr, h_partials, grad_x, stream);
 }
 
 int qiddm_qconv_train_backward_x32(int32_t n_qubits, const float* x, int64_t batch, int64_t in_channels,
@@ -349,14 +430,14 @@ int qiddm_qconv_train_backward_x32(int32_t n_qubits, const float* x, int64_t bat
                                    int32_t row_channels, float* grad_features_t, float* h_partials, double* grad_x,
                                    void* stream) {
   return train_backward(n_qubits, x, true, batch, in_channels, height, width, kh, kw, pad_h, pad_w, grad_y,
-                        out_channels, rows, row_channels, grad_features_t, h_partials, grad_x, stream);
+                        out_channels, rows, row_channels, grad_features_t, nullptr, h_partials, grad_x, stream);
 }
 
 namespace {
 int train_backward(int32_t n_qubits, const void* x, bool x32, int64_t batch, int64_t in_channels, int64_t height,
                    int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, const double* grad_y,
                    int64_t out_channels, const float* rows, int32_t row_channels, float* grad_features_t,
-                   float* h_partials, double* grad_x, void* stream) {
+                   float* pixel_rows, float* h_partials, double* grad_x, void* stream) {
   if (n_qubits < 1 || n_qubits > 12) return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d outside 1..12", n_qubits);
   if (batch < 1 || in_channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad_h < 0 || pad_w < 0 ||
       out_channels < 1)
@@ -370,25 +451,10 @@ int train_backward(int32_t n_qubits, const void* x, bool x32, int64_t batch, int
   const int64_t ho = height + 2 * pad_h - kh + 1, wo = width + 2 * pad_w - kw + 1;
   if (ho < 1 || wo < 1) return fail(QIDDM_ERR_INVALID, "kernel larger than the padded image");
   if (batch * ho * wo >= ((int64_t)1 << 40)) return fail(QIDDM_ERR_INVALID, "too many output pixels");
-  if (!x || !grad_y || !rows || !grad_features_t || !h_partials)
+  if (!x || !grad_y || !rows || (!grad_features_t && !pixel_rows) || !h_partials)
     return fail(QIDDM_ERR_INVALID, "x/grad_y/rows/grad_features_t/h_partials is NULL");
   const int jch = (int)((f + 1 + qiddm::kTcThreads - 1) / qiddm::kTcThreads);
-  qiddm::TrainConv tc;
-  std::memset(&tc, 0, sizeof(tc));
-  tc.C = (int32_t)in_channels;
-  tc.H = (int32_t)height;
-  tc.W = (int32_t)width;
-  tc.kh = (int32_t)kh;
-  tc.kw = (int32_t)kw;
-  tc.ph = (int32_t)pad_h;
-  tc.pw = (int32_t)pad_w;
-  tc.Ho = (int32_t)ho;
-  tc.Wo = (int32_t)wo;
-  tc.C_out = (int32_t)out_channels;
-  tc.F = (int32_t)f;
-  tc.M = batch * ho * wo;
-  tc.pad_norm2 = 0.25f * (float)(d - f);
-  tc.post_scale = 0.5f * (float)d;
+  qiddm::TrainConv tc = train_geometry(n_qubits, batch, in_channels, height, width, kh, kw, pad_h, pad_w, out_channels);
   tc.groups = train_groups(f);
   tc.stamps = qiddm_capi::stamp_buffer(8);
   const unsigned grid = (unsigned)train_grid(batch * ho * wo, f);
@@ -424,9 +490,32 @@ int train_backward(int32_t n_qubits, const void* x, bool x32, int64_t batch, int
     const hipError_t ea = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
     if (ea != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
   }
+  DxChoice dx;
+  if (pixel_rows) {
+    dx = train_dx_choice(tc, row_channels, tm.kern != nullptr);
+    if (!dx.kern) return fail(QIDDM_ERR_UNSUPPORTED, "the per-pixel-row route does not take this layer");
+    tc.wpix = pixel_rows;
+  }
   void* args[] = {(void*)&x, (void*)&grad_y, (void*)&rows, (void*)&grad_features_t, (void*)&h_partials, (void*)&tc};
   hipError_t e = hipLaunchKernel(kern, dim3(grid), dim3(threads), args, smem, st);
   if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_train_backward_kernel launch failed: %s", hipGetErrorString(e));
+  if (pixel_rows) {
+    if (dx.smem > 48 * 1024) {
+      const hipError_t ea = hipFuncSetAttribute(dx.kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+      if (ea != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
+    }
+    // resident workgroups only (each stages the rows table once and walks its tiles): up to eight per CU by threads
+    const int64_t dtiles = (tc.M + qiddm::kDxTile - 1) / qiddm::kDxTile;
+    const int64_t per_cu = std::min<int64_t>(8, (int64_t)(kMaxLds / (dx.smem + 1024)));
+    const int64_t resident = 256 * std::max<int64_t>(1, per_cu);
+    const unsigned dgrid = (unsigned)(dtiles < resident ? dtiles : resident);
+    const double* xd = static_cast<const double*>(x);
+    const float* wp = pixel_rows;
+    void* dargs[] = {(void*)&xd, (void*)&wp, (void*)&rows, (void*)&grad_x, (void*)&tc};
+    e = hipLaunchKernel(dx.kern, dim3(dgrid), dim3(qiddm::kDxThreads), dargs, dx.smem, st);
+    if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_dx_kernel launch failed: %s", hipGetErrorString(e));
+    return QIDDM_OK;
+  }
   if (grad_x) {
     e = qiddm::launch_fold_t(grad_features_t, grad_x, batch, tc, st);
     if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_fold_t_kernel launch failed: %s", hipGetErrorString(e));

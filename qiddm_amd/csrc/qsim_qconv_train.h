@@ -32,6 +32,8 @@ struct TrainConv {
   float pad_norm2;    // 0.25 * (D - F)
   float post_scale;   // D / 2
   unsigned long long* stamps;  // diagnostics (QIDDM_STAMP_PTR): per-phase s_memtime sums of workgroup 0, else null
+  float* wpix;        // matrix-core kernel: per-pixel rows [M][2 CO] of 2 W2 / |v|, then [M] of dot / |v|^2, INSTEAD of
+                      // gfeat_t (qsim_qconv_dx.h turns them into dL/dx); null: feature gradients + fold
 };
 
 constexpr int kTcWaves = 8;                  // wavefronts per workgroup: they split the feature columns of a tile

@@ -374,7 +374,17 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
     //      pixel) a lane holds four CONSECUTIVE pixels per register quad: one 16-byte store per quad into the
     //      pixel-contiguous gfeat_t (a quarter of the store instructions of a dword-per-lane epilogue; the four quads
     //      of the two lane halves complete every 128-byte row segment)
-    {
+    if (tc.wpix != nullptr) {
+      // the per-pixel rows of qconv_dx_kernel instead (qsim_qconv_dx.h): the fold commutes with this product, so dL/dx
+      // is made from 2 CO + 1 floats per pixel and the F x M feature gradients are never written
+      float* __restrict__ wrow = tc.wpix + (size_t)m_base * K2;
+      for (int i = tid; i < kTmTile * K2; i += kTmThreads) {
+        const int m = i / K2, cc = i - m * K2;
+        if (m_base + m < tc.M) wrow[i] = 2.0f * s_w3[m * WS + cc];
+      }
+      if (tid < kTmTile && m_base + tid < tc.M)
+        tc.wpix[(size_t)tc.M * K2 + m_base + tid] = s_dot[tid] * s_inv[tid] * s_inv[tid];
+    } else {
       const int n_units = 2 * ((F + 31) / 32);
       const bool vec_ok = (tc.M & 3) == 0;
       for (int unit = q; unit < n_units; unit += kTmWaves) {

@@ -81,8 +81,11 @@ class QConv2d(torch.nn.Module):
                 and _c.qconv_unitary_trainable(self.wires, self.in_channels, self.kernel_size, self.out_channels)):
             # training through the circuit unitary: GEMM forward, thin-product backward, one adjoint sweep per
             # output channel (the circuit does not depend on the data)
-            return _c.qconv_unitary_execute(x.double(), _qw_tanh(self.weights.double()), self.wires,
-                                            self.out_channels, self.kernel_size, self.padding)
+            # (the angle map runs on the weight-gradient stream: its backward, and the adjoint sweeps in front of it,
+            #  then overlap the rest of the network's backward -- circuit.on_weight_grad_stream)
+            angles = _c.on_weight_grad_stream(lambda w: _qw_tanh(w.double()), self.weights)
+            return _c.qconv_unitary_execute(x.double(), angles, self.wires, self.out_channels, self.kernel_size,
+                                            self.padding)
         if (self.qnode is self._own_qnode and self.wires <= 10 and x.is_cuda
                 and 2 * self.out_channels <= 2 ** self.wires):
             # training: the same fused launch, differentiable (adjoint sweep per output pixel + fold)

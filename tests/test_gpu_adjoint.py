@@ -153,8 +153,9 @@ def test_thin_product_backward_float32_activations_and_generic_walk(c_in, c_out,
     x = torch.rand(3, c_in, *hw, dtype=torch.float64, device="cuda")
     gy = torch.randn(3, c_out, hw[0] + 2 * pad - k + 1, hw[1] + 2 * pad - k + 1, dtype=torch.float64, device="cuda")
 
-    def grads(x32):
+    def grads(x32, dx=False):
         monkeypatch.setattr(circuit, "_QCONV_X32", x32)
+        monkeypatch.setattr(circuit, "_QCONV_DX", dx)
         xg = x.clone().requires_grad_(True)
         gx, gw = torch.autograd.grad(layer(xg), [xg, layer.weights], gy)
         return gx, gw
@@ -162,6 +163,15 @@ def test_thin_product_backward_float32_activations_and_generic_walk(c_in, c_out,
     gx64, gw64 = grads(False)
     gx32, gw32 = grads(True)
     assert torch.equal(gx64, gx32) and torch.equal(gw64, gw32)
+    # dL/dx from the per-pixel rows (qiddm_qconv_train_backward_dx: no feature-gradient matrix, the taps summed in float32
+    # on the matrix cores) against the fold route: same weight gradients bit for bit, dL/dx to float32 rounding
+    lib = circuit._capi.lib()
+    co = circuit._row_channels(c_out)
+    takes_dx = lib.qiddm_qconv_train_dx_elems(layer.wires, 3, c_in, hw[0], hw[1], k, k, pad, pad, c_out, co) > 0
+    assert takes_dx == (c_in <= 32), "every same-size layer up to 32 input channels takes the per-pixel-row route"
+    gxd, gwd = grads(False, dx=True)
+    assert torch.equal(gwd, gw64)
+    assert torch.allclose(gxd, gx64, rtol=0, atol=2e-6 * max(1.0, gx64.abs().max().item())), (gxd - gx64).abs().max()
     # against autograd through the oracle
     xo = x.cpu().requires_grad_(True)
     wo = layer.weights.detach().cpu().clone().requires_grad_(True)

@@ -240,3 +240,41 @@ def test_recorded_data_parallel_step_with_rccl_in_the_graph():
     assert losses_r == pytest.approx(losses_e, rel=1e-9, abs=1e-12)
     for (k, a), (_, b) in zip(eager.state_dict().items(), rec.state_dict().items()):
         assert torch.allclose(a, b, rtol=1e-7, atol=1e-10), k
+
+
+def test_weight_gradient_side_stream_leaves_the_same_gradients(monkeypatch):
+    """The convolutions' weight-gradient chains run on a side stream (circuit.on_weight_grad_stream): the same kernels on
+    the same data, so every gradient equals the single-stream run bit for bit -- over several steps back to back, so
+    that a missing join between the side stream and the optimizer (or the next forward) would show."""
+    from qiddm_amd import circuit, models, nn, noise
+
+    def run(side):
+        monkeypatch.setattr(circuit, "_WEIGHT_GRAD_STREAM", side)
+        torch.manual_seed(5)
+        net = nn.UNetUndirectedS(2, 4, 2)
+        diff = models.Diffusion(net, noise.add_normal_noise_multiple, "data", (8, 8),
+                                torch.nn.MSELoss()).to("cuda", dtype=torch.double).train()
+        opt = torch.optim.Adam(diff.parameters(), lr=1e-2)
+        g = torch.Generator(device="cuda").manual_seed(9)
+        grads, losses = [], []
+        torch.manual_seed(11)
+        for _ in range(4):
+            x = torch.rand(6, 64, dtype=torch.double, device="cuda", generator=g)
+            opt.zero_grad()
+            (loss,) = diff(x=x, T=3)
+            grads.append({k: p.grad.clone() for k, p in diff.named_parameters() if p.grad is not None})
+            opt.step()
+            losses.append(loss.item())
+        return grads, losses, {k: v.clone() for k, v in diff.state_dict().items()}
+
+    g1, l1, s1 = run(True)
+    assert circuit.weight_grad_stream(torch.device("cuda", 0)) is not None
+    g0, l0, s0 = run(False)
+    assert circuit.weight_grad_stream(torch.device("cuda", 0)) is None
+    assert l1 == l0
+    for a, b in zip(g1, g0):
+        assert a.keys() == b.keys() and any("weights" in k for k in a)
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+    for k in s1:
+        assert torch.equal(s1[k], s0[k]), k
