@@ -426,6 +426,13 @@ int qiddm_upsample2x_forward(const double *x, int64_t planes, int64_t height, in
 int qiddm_upsample2x_backward(const double *grad_y, int64_t planes, int64_t height, int64_t width,
                               const double *ah, const double *aw, double *grad_x, void *stream);
 
+/* MaxPool2d(kernel_size=2, stride=2) of the UNets' down blocks (reference nn/unet.py:93-95), float64 (planes, H, W) ->
+ * (planes, H/2, W/2), floor mode.  The backward recomputes the winner of every window from x (first maximum in row-major
+ * order, as torch picks it) instead of keeping an index tensor and writes every element of grad_x once.         */
+int qiddm_maxpool2_forward(const double *x, int64_t planes, int64_t height, int64_t width, double *y, void *stream);
+int qiddm_maxpool2_backward(const double *x, const double *grad_y, int64_t planes, int64_t height, int64_t width,
+                            double *grad_x, void *stream);
+
 /* ---- quantum convolution backward through the circuit unitary (training) ----------------------------------
  * The circuit of QConv2d does not depend on the data (reference nn/qconv.py:51-56), so with U = U(weights):
  * a_mc = sum_j U[2c,j] v^_mj, y_mc = clamp(|a_mc|^2 D/2) for every output pixel m -- and the backward needs no
@@ -496,6 +503,14 @@ int qiddm_matrix_adjoint(const qiddm_circuit_t *circ, const double *psi0, const 
  * x (batch, in_channels, hw), weight (out_channels, in_channels), bias (out_channels) or NULL.          */
 int qiddm_conv1x1_forward(const double *x, const double *weight, const double *bias, int64_t batch,
                           int64_t in_channels, int64_t out_channels, int64_t hw, double *y, void *stream);
+/* backward of the ONE-output-channel head (torch autograd through `final_conv`, reference nn/unet.py:160-166, 177):
+ * grad_x[b, c, p] = weight[c] grad_y[b, p], grad_weight[c] = sum grad_y x, grad_bias = sum grad_y -- one pass over x and
+ * grad_y, per-workgroup partial sums (`partials`: qiddm_conv1x1_head_partials() x (in_channels + 1) float64) added in a
+ * fixed order.  in_channels <= 32; grad_x / grad_weight / grad_bias may each be NULL.                            */
+int64_t qiddm_conv1x1_head_partials(int64_t batch, int64_t hw);
+int qiddm_conv1x1_head_backward(const double *x, const double *weight, const double *grad_y, int64_t batch,
+                                int64_t in_channels, int64_t hw, double *grad_x, double *grad_weight,
+                                double *grad_bias, double *partials, void *stream);
 
 /* ---- density-matrix execution (hardware-noise study) ---------------------------------------------
  * Replaces PennyLane's `default.mixed` for the circuits the `*_noise.py` drivers run at sampling time

@@ -62,7 +62,11 @@ EXPORTS = (
     "qiddm_circuit_unitary_wide",
     "qiddm_qconv_unitary_workspace_bytes",
     "qiddm_qconv_unitary_forward",
+    "qiddm_maxpool2_forward",
+    "qiddm_maxpool2_backward",
     "qiddm_conv1x1_forward",
+    "qiddm_conv1x1_head_partials",
+    "qiddm_conv1x1_head_backward",
     "qiddm_qconv_fold_features",
     "qiddm_qconv_train_rows",
     "qiddm_qconv_train_vectors",
@@ -231,8 +235,16 @@ def _declare(lib):
     lib.qiddm_mixed_forward.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(MixedOp), ctypes.c_int32, vp, i64,
                                         ctypes.c_int32, vp, i64, ctypes.c_int32, ctypes.c_double, ctypes.c_double, vp,
                                         ctypes.c_int32, ctypes.c_int32, i64, vp, i64, vp, i64, vp]
+    lib.qiddm_maxpool2_forward.restype = ctypes.c_int
+    lib.qiddm_maxpool2_forward.argtypes = [vp, i64, i64, i64, vp, vp]
+    lib.qiddm_maxpool2_backward.restype = ctypes.c_int
+    lib.qiddm_maxpool2_backward.argtypes = [vp, vp, i64, i64, i64, vp, vp]
     lib.qiddm_conv1x1_forward.restype = ctypes.c_int
     lib.qiddm_conv1x1_forward.argtypes = [vp, vp, vp, i64, i64, i64, i64, vp, vp]
+    lib.qiddm_conv1x1_head_partials.restype = ctypes.c_int64
+    lib.qiddm_conv1x1_head_partials.argtypes = [i64, i64]
+    lib.qiddm_conv1x1_head_backward.restype = ctypes.c_int
+    lib.qiddm_conv1x1_head_backward.argtypes = [vp, vp, vp, i64, i64, i64, vp, vp, vp, vp, vp]
     lib.qiddm_adam_step.restype = ctypes.c_int
     lib.qiddm_adam_step.argtypes = [ctypes.POINTER(AdamTensor), ctypes.c_int32, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_double, ctypes.c_double, ctypes.c_double, vp, vp]

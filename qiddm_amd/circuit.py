@@ -490,6 +490,45 @@ def conv1x1_forward(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor
     return y
 
 
+class _Conv1x1HeadFunction(torch.autograd.Function):
+    """The UNets' one-channel ``final_conv`` (reference nn/unet.py:160-166) for training: ``qiddm_conv1x1_forward``, and
+    the whole backward -- grad_x, grad_weight, grad_bias -- in one pass (``qiddm_conv1x1_head_backward``)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        y = conv1x1_forward(x, weight, bias)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        device = x.device
+        xx = _as_f64(x, device).contiguous()
+        b, c, h, w = xx.shape
+        g = _as_f64(gy, device).contiguous()
+        wt = _as_f64(weight.detach(), device).reshape(-1).contiguous()
+        lib = _capi.lib()
+        gx = torch.empty_like(xx) if ctx.needs_input_grad[0] else None
+        gw = torch.empty(c, dtype=torch.float64, device=device) if ctx.needs_input_grad[1] else None
+        gb = torch.empty(1, dtype=torch.float64, device=device) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        part = torch.empty(lib.qiddm_conv1x1_head_partials(b, h * w), c + 1, dtype=torch.float64, device=device)
+
+        def ptr(t):
+            return 0 if t is None else t.data_ptr()
+
+        _capi.check(lib.qiddm_conv1x1_head_backward(xx.data_ptr(), wt.data_ptr(), g.data_ptr(), b, c, h * w, ptr(gx),
+                                                    ptr(gw), ptr(gb), part.data_ptr(), _stream_ptr(device)))
+        return (None if gx is None else gx.to(x.dtype)), (None if gw is None else gw.reshape(weight.shape).to(weight.dtype)), \
+            (None if gb is None else gb)
+
+
+def conv1x1_head(x: torch.Tensor, weight: torch.Tensor, bias) -> torch.Tensor:
+    """Differentiable float64 1x1 convolution to ONE channel with at most 32 input channels (the UNets' head)."""
+    return _Conv1x1HeadFunction.apply(x, weight, bias)
+
+
 _train_workspaces = {}
 
 
@@ -996,6 +1035,42 @@ class _Upsample2xFunction(torch.autograd.Function):
         _capi.check(_capi.lib().qiddm_upsample2x_backward(gy.data_ptr(), b * c, h, w, a_h.data_ptr(), a_w.data_ptr(),
                                                           gx.data_ptr(), _stream_ptr(gy.device)))
         return gx, None, None
+
+
+class _MaxPool2Function(torch.autograd.Function):
+    """``MaxPool2d(2, 2)`` of a float64 (B, C, H, W) tensor (``qiddm_maxpool2_forward`` / ``_backward``): no index
+    tensor, the backward finds the winners again from the saved input."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        b, c, h, w = x.shape
+        y = torch.empty(b, c, h // 2, w // 2, dtype=torch.float64, device=x.device)
+        _capi.check(_capi.lib().qiddm_maxpool2_forward(x.data_ptr(), b * c, h, w, y.data_ptr(), _stream_ptr(x.device)))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        b, c, h, w = x.shape
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        _capi.check(_capi.lib().qiddm_maxpool2_backward(x.data_ptr(), gy.data_ptr(), b * c, h, w, gx.data_ptr(),
+                                                        _stream_ptr(x.device)))
+        return gx
+
+
+def max_pool2(pool: torch.nn.MaxPool2d, x: torch.Tensor) -> torch.Tensor:
+    """``pool(x)`` through the HIP kernels when it is the UNets' ``MaxPool2d(kernel_size=2, stride=2)`` on a float64 device
+    tensor of at least 2 x 2 pixels; anything else goes to the torch module."""
+    def two(v):
+        return v in (2, (2, 2))
+    if not (isinstance(pool, torch.nn.MaxPool2d) and two(pool.kernel_size) and two(pool.stride) and pool.padding in (0, (0, 0))
+            and pool.dilation in (1, (1, 1)) and not pool.ceil_mode and not pool.return_indices and x.is_cuda
+            and x.dtype == torch.float64 and x.dim() == 4 and x.numel() > 0 and x.shape[2] >= 2 and x.shape[3] >= 2):
+        return pool(x)
+    return _MaxPool2Function.apply(x)
 
 
 def upsample2x(x: torch.Tensor, a_h: torch.Tensor, a_w: torch.Tensor) -> torch.Tensor:

@@ -367,6 +367,62 @@ __global__ __launch_bounds__(256) void upsample2x_backward_lds_kernel(const doub
   }
 }
 
+// ---- MaxPool2d(kernel 2, stride 2) of the down blocks (reference nn/unet.py:93-95), float64, floor mode -----------------
+// forward: one thread per output element; backward: one thread per output element recomputes which of its four inputs
+// won (the first maximum in row-major window order, as torch's kernel picks it; a NaN wins) and writes all four input
+// gradients -- no index tensor (torch keeps one int64 per output), every element of grad_x written exactly once.
+__global__ __launch_bounds__(256) void maxpool2_forward_kernel(const double* __restrict__ x, int64_t planes, int H, int W,
+                                                               double* __restrict__ y) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= planes * Ho * Wo) return;
+  const int j = (int)(idx % Wo);
+  const int i = (int)((idx / Wo) % Ho);
+  const int64_t plane = idx / ((int64_t)Wo * Ho);
+  const double* __restrict__ src = x + plane * H * W + (size_t)(2 * i) * W + 2 * j;
+  const double v[4] = {src[0], src[1], src[W], src[W + 1]};
+  double m = v[0];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) m = (v[k] > m || v[k] != v[k]) ? v[k] : m;
+  y[idx] = m;
+}
+
+__global__ __launch_bounds__(256) void maxpool2_backward_kernel(const double* __restrict__ x, const double* __restrict__ gy,
+                                                                int64_t planes, int H, int W, double* __restrict__ gx) {
+  const int Ho = H / 2, Wo = W / 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= planes * Ho * Wo) return;
+  const int j = (int)(idx % Wo);
+  const int i = (int)((idx / Wo) % Ho);
+  const int64_t plane = idx / ((int64_t)Wo * Ho);
+  const size_t at = (size_t)plane * H * W + (size_t)(2 * i) * W + 2 * j;
+  const double v[4] = {x[at], x[at + 1], x[at + W], x[at + W + 1]};
+  double m = v[0];
+  int win = 0;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    if (v[k] > m || v[k] != v[k]) {
+      m = v[k];
+      win = k;
+    }
+  }
+  const double g = gy[idx];
+  gx[at] = win == 0 ? g : 0.0;
+  gx[at + 1] = win == 1 ? g : 0.0;
+  gx[at + W] = win == 2 ? g : 0.0;
+  gx[at + W + 1] = win == 3 ? g : 0.0;
+  // an odd last row / column belongs to no window
+  if (j == Wo - 1 && (W & 1)) {
+    gx[at + 2] = 0.0;
+    gx[at + W + 2] = 0.0;
+  }
+  if (i == Ho - 1 && (H & 1)) {
+    gx[at + 2 * W] = 0.0;
+    gx[at + 2 * W + 1] = 0.0;
+    if (j == Wo - 1 && (W & 1)) gx[at + 2 * W + 2] = 0.0;
+  }
+}
+
 }  // namespace qiddm
 
 namespace {
@@ -478,6 +534,29 @@ int qiddm_upsample2x_backward(const double* grad_y, int64_t planes, int64_t heig
   hipLaunchKernelGGL(qiddm::upsample2x_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), grad_y, ah, aw, planes, (int)height, (int)width, grad_x);
   return launched("upsample2x_backward_kernel");
+}
+
+int qiddm_maxpool2_forward(const double* x, int64_t planes, int64_t height, int64_t width, double* y, void* stream) {
+  if (planes < 1 || height < 2 || width < 2 || height > (1 << 14) || width > (1 << 14))
+    return fail(QIDDM_ERR_INVALID, "bad max-pool geometry");
+  if (!x || !y) return fail(QIDDM_ERR_INVALID, "x/y is NULL");
+  const int64_t total = planes * (height / 2) * (width / 2);
+  if (total >= ((int64_t)1 << 39)) return fail(QIDDM_ERR_UNSUPPORTED, "tensor too large for one launch");
+  hipLaunchKernelGGL(qiddm::maxpool2_forward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, planes, (int)height, (int)width, y);
+  return launched("maxpool2_forward_kernel");
+}
+
+int qiddm_maxpool2_backward(const double* x, const double* grad_y, int64_t planes, int64_t height, int64_t width,
+                            double* grad_x, void* stream) {
+  if (planes < 1 || height < 2 || width < 2 || height > (1 << 14) || width > (1 << 14))
+    return fail(QIDDM_ERR_INVALID, "bad max-pool geometry");
+  if (!x || !grad_y || !grad_x) return fail(QIDDM_ERR_INVALID, "x/grad_y/grad_x is NULL");
+  const int64_t total = planes * (height / 2) * (width / 2);
+  if (total >= ((int64_t)1 << 39)) return fail(QIDDM_ERR_UNSUPPORTED, "tensor too large for one launch");
+  hipLaunchKernelGGL(qiddm::maxpool2_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), x, grad_y, planes, (int)height, (int)width, grad_x);
+  return launched("maxpool2_backward_kernel");
 }
 
 }  // extern "C"

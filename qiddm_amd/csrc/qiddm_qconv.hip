@@ -601,4 +601,36 @@ int qiddm_conv1x1_forward(const double* x, const double* weight, const double* b
   return QIDDM_OK;
 }
 
+int64_t qiddm_conv1x1_head_partials(int64_t batch, int64_t hw) {
+  if (batch < 0 || hw < 0) return -1;
+  const int64_t blocks = (batch * hw + 255) / 256;
+  return blocks < 1 ? 1 : (blocks < 2048 ? blocks : 2048);
+}
+
+int qiddm_conv1x1_head_backward(const double* x, const double* weight, const double* grad_y, int64_t batch,
+                                int64_t in_channels, int64_t hw, double* grad_x, double* grad_weight,
+                                double* grad_bias, double* partials, void* stream) {
+  if (batch < 1 || in_channels < 1 || hw < 1) return fail(QIDDM_ERR_INVALID, "bad 1x1 convolution geometry");
+  if (in_channels > qiddm::kHeadMaxC)
+    return fail(QIDDM_ERR_UNSUPPORTED, "head backward: at most %d input channels", qiddm::kHeadMaxC);
+  if (!x || !weight || !grad_y || !partials) return fail(QIDDM_ERR_INVALID, "x/weight/grad_y/partials is NULL");
+  const int64_t total = batch * hw;
+  const int64_t grid = qiddm_conv1x1_head_partials(batch, hw);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (in_channels <= 8)
+    hipLaunchKernelGGL(qiddm::conv1x1_head_backward_kernel<8>, dim3((unsigned)grid), dim3(256), 0, st, x, weight, grad_y,
+                       total, hw, (int)in_channels, grad_x, partials);
+  else if (in_channels <= 16)
+    hipLaunchKernelGGL(qiddm::conv1x1_head_backward_kernel<16>, dim3((unsigned)grid), dim3(256), 0, st, x, weight,
+                       grad_y, total, hw, (int)in_channels, grad_x, partials);
+  else
+    hipLaunchKernelGGL(qiddm::conv1x1_head_backward_kernel<32>, dim3((unsigned)grid), dim3(256), 0, st, x, weight,
+                       grad_y, total, hw, (int)in_channels, grad_x, partials);
+  hipLaunchKernelGGL(qiddm::conv1x1_head_finalize_kernel, dim3(1), dim3(256), 0, st, partials, (int)grid,
+                     (int)in_channels, grad_weight, grad_bias);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "conv1x1_head_backward launch failed: %s", hipGetErrorString(e));
+  return QIDDM_OK;
+}
+
 }  // extern "C"

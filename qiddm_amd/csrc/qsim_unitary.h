@@ -563,4 +563,79 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(const double* __restrict__
   }
 }
 
+// backward of the one-output-channel head in ONE pass over x and grad_y: gx[b, c, p] = w[c] gy[b, p] written while
+// gw[c] += gy x and gb += gy accumulate in registers; per-workgroup partial sums [grid][c_in + 1] are summed in a fixed
+// order by conv1x1_head_finalize_kernel (deterministic, no atomics).  (torch autograd ran five launches over the
+// same tensors, one of them materialising x * w.)
+constexpr int kHeadMaxC = 32;
+// (CMAX: register arrays of 8 / 16 / 32 channels -- 8 keeps four workgroups per CU resident)
+template <int CMAX>
+__global__ __launch_bounds__(256) void conv1x1_head_backward_kernel(const double* __restrict__ x,
+                                                                    const double* __restrict__ w,
+                                                                    const double* __restrict__ gy, int64_t total,
+                                                                    int64_t hw, int c_in, double* __restrict__ gx,
+                                                                    double* __restrict__ partial) {
+  __shared__ double s_red[4];
+  double wv[CMAX], acc[CMAX + 1];   // acc[CMAX]: the bias gradient
+#pragma unroll
+  for (int c = 0; c < CMAX; ++c) {
+    wv[c] = c < c_in ? w[c] : 0.0;
+    acc[c] = 0.0;
+  }
+  acc[CMAX] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / hw, px = i - b * hw;
+    const size_t base = (size_t)b * c_in * hw + px;
+    const double g = gy[i];
+    acc[CMAX] += g;
+    double xv[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) xv[c] = c < c_in ? x[base + (size_t)c * hw] : 0.0;
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c) {
+      if (c < c_in) {
+        if (gx) gx[base + (size_t)c * hw] = wv[c] * g;
+        acc[c] = fma(g, xv[c], acc[c]);
+      }
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double* __restrict__ out = partial + (size_t)blockIdx.x * (c_in + 1);
+#pragma unroll
+  for (int c = 0; c <= CMAX; ++c) {
+    if (c < c_in || c == CMAX) {   // (uniform)
+      double v = acc[c];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      __syncthreads();
+      if (lane == 0) s_red[wave] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) out[c == CMAX ? c_in : c] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv1x1_head_finalize_kernel(const double* __restrict__ partial, int n_partials,
+                                                                    int c_in, double* __restrict__ gw,
+                                                                    double* __restrict__ gb) {
+  // one workgroup: thread t adds partials t, t + 256, ... of a column, then the 256 sums are added in a fixed tree
+  __shared__ double s_red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = 0; c <= c_in; ++c) {
+    double v = 0.0;
+    for (int p = threadIdx.x; p < n_partials; p += 256) v += partial[(size_t)p * (c_in + 1) + c];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    __syncthreads();
+    if (lane == 0) s_red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double s = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+      if (c < c_in) {
+        if (gw) gw[c] = s;
+      } else if (gb) {
+        gb[0] = s;
+      }
+    }
+  }
+}
+
 }  // namespace qiddm

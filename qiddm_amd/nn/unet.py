@@ -80,7 +80,7 @@ class DownBlock(torch.nn.Module):
 
     def forward(self, x):
         before_pool = _run(self.net, x.to(F64))
-        return (self.pooling_layer(before_pool) if self.pooling else before_pool), before_pool
+        return (_c.max_pool2(self.pooling_layer, before_pool) if self.pooling else before_pool), before_pool
 
 
 class UNetUndirected(torch.nn.Module):

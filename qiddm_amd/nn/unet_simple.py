@@ -44,7 +44,7 @@ class DownBlockS(DownBlock):
         before_pool = _fused_conv_bn(self.net, x)
         if before_pool is None:
             return super().forward(x)
-        return (self.pooling_layer(before_pool) if self.pooling else before_pool), before_pool
+        return (_c.max_pool2(self.pooling_layer, before_pool) if self.pooling else before_pool), before_pool
 
 
 class UpBlockS(UpBlock):

@@ -25,6 +25,8 @@ def autopad(x, y):
         warnings.warn("x is smaller than y. Padding x to match y")
         return autopad(y, x)
     dh, dw = x.shape[2] - y.shape[2], x.shape[3] - y.shape[3]
+    if dh == 0 and dw == 0:
+        return x, y              # (F.pad with all-zero pads is a full copy of y: 128 MB per up block at batch 2560)
     pads = (math.ceil(dw / 2), math.floor(dw / 2), math.ceil(dh / 2), math.floor(dh / 2))
     return x, F.pad(y, pads, mode="constant", value=0)
 
@@ -58,6 +60,10 @@ def unfold_patches(x: torch.Tensor, kernel_size, padding) -> torch.Tensor:
 def pointwise_conv(conv: torch.nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     """A 1x1, stride-1, ungrouped ``Conv2d`` as one matrix product over the channel axis."""
     w = conv.weight[:, :, 0, 0]
+    if w.shape[0] == 1 and w.shape[1] <= 32 and x.is_cuda and x.dtype == torch.float64 and w.dtype == torch.float64 \
+            and x.dim() == 4 and x.numel() > 0 and (conv.bias is None or conv.bias.dtype == torch.float64):
+        from .. import circuit as _c
+        return _c.conv1x1_head(x, conv.weight, conv.bias)      # forward + one-pass backward in HIP
     if w.shape[0] == 1:
         # one output channel (the UNets' head): a weighted channel sum -- its weight gradient is then a plain
         # reduction instead of a (1 x C) product over B*H*W terms, which the BLAS handles badly

@@ -454,3 +454,51 @@ def test_probability_nets_fused_post_processing_tracks_weight_updates():
             ref = oc.qdense_undirected_forward(x.cpu(), net2.weights.detach().cpu().double(), (8, 8), weight_map="tanh")
             assert torch.allclose(got, ref, atol=2e-3), (got - ref).abs().max()
             net2.weights.add_(0.2)
+
+
+@pytest.mark.parametrize("b,c,h,w,bias", [(3, 8, 28, 28, True), (1, 1, 1, 1, True), (5, 13, 7, 9, False), (2, 32, 6, 5, True),
+                                          (700, 8, 4, 4, True)])
+def test_hip_one_channel_head_matches_torch_conv(b, c, h, w, bias):
+    """The UNets' final 1x1 convolution to one channel (qiddm_conv1x1_forward + the one-pass
+    qiddm_conv1x1_head_backward) against torch's own float64 Conv2d: output and all three gradients; sizes on either
+    side of the 8 / 16 / 32 channel variants and more pixels than one round of workgroups."""
+    from qiddm_amd.nn.utils import pointwise_conv
+    torch.manual_seed(b + c)
+    ref = torch.nn.Conv2d(c, 1, 1, bias=bias).to(DEV, torch.double)
+    mine = torch.nn.Conv2d(c, 1, 1, bias=bias).to(DEV, torch.double)
+    mine.load_state_dict(ref.state_dict())
+    x = torch.randn(b, c, h, w, dtype=torch.float64, device=DEV)
+    g = torch.randn(b, 1, h, w, dtype=torch.float64, device=DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = (xa * ref.weight.view(1, -1, 1, 1)).sum(dim=1, keepdim=True) + (ref.bias.view(1, 1, 1, 1) if bias else 0.0)
+    yb = pointwise_conv(mine, xb)
+    assert type(yb.grad_fn).__name__ == "_Conv1x1HeadFunctionBackward"
+    (ya * g).sum().backward()
+    (yb * g).sum().backward()
+    assert torch.allclose(ya, yb, rtol=1e-13, atol=1e-13)
+    assert torch.allclose(xa.grad, xb.grad, rtol=1e-13, atol=1e-13)
+    assert torch.allclose(ref.weight.grad, mine.weight.grad, rtol=1e-11, atol=1e-11), (ref.weight.grad - mine.weight.grad).abs().max()
+    if bias:
+        assert torch.allclose(ref.bias.grad, mine.bias.grad, rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("shape", [(3, 8, 28, 28), (2, 3, 7, 9), (1, 1, 2, 2), (5, 2, 3, 2), (40, 16, 14, 14)])
+def test_hip_maxpool2_matches_torch(shape):
+    """qiddm_maxpool2_forward / _backward against torch.nn.MaxPool2d(2, 2) in float64: odd extents (the last row / column
+    belongs to no window and gets a zero gradient) and ties (the first maximum of a window takes the gradient)."""
+    from qiddm_amd.circuit import max_pool2
+    torch.manual_seed(sum(shape))
+    pool = torch.nn.MaxPool2d(kernel_size=2, stride=2)
+    x = torch.randn(*shape, dtype=torch.float64, device=DEV)
+    x = torch.round(x * 2) / 2                                   # many exact ties inside the windows
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = pool(xa), max_pool2(pool, xb)
+    assert type(yb.grad_fn).__name__ == "_MaxPool2FunctionBackward"
+    g = torch.randn_like(ya)
+    (ya * g).sum().backward()
+    (yb * g).sum().backward()
+    assert torch.equal(ya, yb)
+    assert torch.equal(xa.grad, xb.grad)
+    # other pooling geometries stay with torch
+    other = torch.nn.MaxPool2d(kernel_size=3, stride=2)
+    assert torch.equal(max_pool2(other, x), other(x)) if shape[2] >= 3 and shape[3] >= 3 else True
