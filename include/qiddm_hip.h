@@ -410,6 +410,13 @@ int qiddm_batchnorm_train_forward(const double *x, int64_t batch, int64_t channe
                                   const double *weight, const double *bias, double *running_mean,
                                   double *running_var, double momentum, double eps, double *y, double *save_mean,
                                   double *save_invstd, void *workspace, int64_t workspace_bytes, void *stream);
+/* the statistics half of the backward only: grad_weight / grad_bias (each may be NULL) and coef (3, channels) with
+ * dL/dx = coef[0][c] grad_y + coef[1][c] x + coef[2][c] -- for a producer that applies it itself
+ * (qiddm_qconv_train_backward_bn).  Same workspace as qiddm_batchnorm_backward.                               */
+int qiddm_batchnorm_backward_stats(const double *x, const double *grad_y, int64_t batch, int64_t channels, int64_t hw,
+                                   const double *weight, const double *save_mean, const double *save_invstd,
+                                   double *grad_weight, double *grad_bias, double *coef, void *workspace,
+                                   int64_t workspace_bytes, void *stream);
 int qiddm_batchnorm_backward(const double *x, const double *grad_y, int64_t batch, int64_t channels, int64_t hw,
                              const double *weight, const double *save_mean, const double *save_invstd,
                              double *grad_x, double *grad_weight, double *grad_bias, void *workspace,
@@ -493,6 +500,18 @@ int qiddm_qconv_train_backward_dx(int32_t n_qubits, const double *x, int64_t bat
                                   int64_t height, int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
                                   const double *grad_y, int64_t out_channels, const float *rows, int32_t row_channels,
                                   float *pixel_rows, float *h_partials, double *grad_x, void *stream);
+/* The same backward for a convolution that is followed by a training-mode BatchNorm2d (every `net` of unet_simple,
+ * reference nn/unet_simple.py:9-18): grad_out is dL/d(BatchNorm output), conv_y the convolution's own output and
+ * bn_coef the (3, out_channels) coefficients of qiddm_batchnorm_backward_stats; the kernels form
+ * dL/dy = coef[0] grad_out + coef[1] conv_y + coef[2] per channel while they load it, so the BatchNorm backward's
+ * transform pass never runs.  With pixel_rows (qiddm_qconv_train_dx_elems() floats) dL/dx comes from the per-pixel
+ * rows and grad_features_t may be NULL; otherwise as qiddm_qconv_train_backward.                                */
+int qiddm_qconv_train_backward_bn(int32_t n_qubits, const double *x, int64_t batch, int64_t in_channels,
+                                  int64_t height, int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
+                                  const double *grad_out, const double *conv_y, const double *bn_coef,
+                                  int64_t out_channels, const float *rows, int32_t row_channels,
+                                  float *grad_features_t, float *pixel_rows, float *h_partials, double *grad_x,
+                                  void *stream);
 int64_t qiddm_matrix_adjoint_partials(int64_t count);
 int64_t qiddm_matrix_adjoint_workspace_bytes(const qiddm_circuit_t *circ, int64_t count);
 int qiddm_matrix_adjoint(const qiddm_circuit_t *circ, const double *psi0, const double *lambda, int64_t count,

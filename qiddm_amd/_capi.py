@@ -82,6 +82,8 @@ EXPORTS = (
     "qiddm_batchnorm_workspace_bytes",
     "qiddm_batchnorm_train_forward",
     "qiddm_batchnorm_backward",
+    "qiddm_batchnorm_backward_stats",
+    "qiddm_qconv_train_backward_bn",
     "qiddm_upsample2x_forward",
     "qiddm_upsample2x_backward",
     "qiddm_mixed_workspace_bytes",
@@ -213,6 +215,11 @@ def _declare(lib):
     lib.qiddm_batchnorm_workspace_bytes.argtypes = [i64, i64, i64]
     lib.qiddm_batchnorm_train_forward.restype = ctypes.c_int
     lib.qiddm_batchnorm_train_forward.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, dbl, dbl, vp, vp, vp, vp, i64, vp]
+    lib.qiddm_batchnorm_backward_stats.restype = ctypes.c_int
+    lib.qiddm_batchnorm_backward_stats.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.qiddm_qconv_train_backward_bn.restype = ctypes.c_int
+    lib.qiddm_qconv_train_backward_bn.argtypes = [ctypes.c_int32, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, vp, vp,
+                                                  i64, vp, ctypes.c_int32, vp, vp, vp, vp, vp]
     lib.qiddm_batchnorm_backward.restype = ctypes.c_int
     lib.qiddm_batchnorm_backward.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.qiddm_train_workspace_bytes.restype = ctypes.c_int64

@@ -836,6 +836,9 @@ _QCONV_X32 = os.environ.get("QIDDM_QCONV_X32", "0") == "1"
 # QIDDM_QCONV_FOLD=1: keep the (F, M) feature gradients + fold for dL/dx instead of the per-pixel rows + transposed
 # convolution (qiddm_qconv_train_backward_dx); the library reads the same variable
 _QCONV_DX = os.environ.get("QIDDM_QCONV_FOLD") is None
+# QIDDM_QCONV_BN_SPLIT=1: keep [QConv2d, BatchNorm2d] as two autograd nodes in training (no folding of the BatchNorm
+# backward into the convolution's)
+_QCONV_BN_FUSED = os.environ.get("QIDDM_QCONV_BN_SPLIT") is None
 _GEMM_CHUNK_BYTES = 256 << 20      # patch matrix of one batch chunk on the "gemm" route
 
 
@@ -895,46 +898,64 @@ class _QConvUnitaryFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_y):
         x, angles, u = ctx.saved_tensors
-        n_qubits, c_out, (kh, kw), (ph, pw) = ctx.cfg
-        device = x.device
-        b, c, h, w = x.shape
-        f = c * kh * kw
-        ho, wo = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
-        need_gx = ctx.needs_input_grad[0]
-        if qconv_unitary_route(n_qubits, c, (kh, kw), c_out) == "gemm":
-            hpart, gx = _qconv_unitary_backward_gemm(x, grad_y, u, n_qubits, c_out, (kh, kw), (ph, pw), need_gx)
-            ga = _angle_grads_off_stream(hpart, 1, angles, n_qubits, f, c_out, c_out, device) \
-                if ctx.needs_input_grad[1] else None
-            return (None if gx is None else gx.to(x.dtype)), ga, None, None, None, None
-        co = _row_channels(c_out)
-        lib = _capi.lib()
-        st = _stream_ptr(device)
-        rt = _unitary_rows(u, n_qubits, f, c_out, co, device)
-        # the matrix-core kernel converts every patch element to float32 anyway: hand it a float32 copy (one elementwise
-        # pass; its gather then holds half the bytes in flight)
-        x32 = _QCONV_X32 and bool(lib.qiddm_qconv_train_x32_ok(b, c, h, w, kh, kw, ph, pw, c_out, co))
-        xx = x.detach().to(device=device, dtype=torch.float32).contiguous() if x32 else _as_f64(x, device).contiguous()
-        gy = _as_f64(grad_y, device).contiguous()
-        n_part = lib.qiddm_qconv_train_partials(b, ho, wo, f)
-        hpart = torch.empty(n_part, 2 * co, f + 1, dtype=torch.float32, device=device)
-        gx = torch.empty(b, c, h, w, dtype=torch.float64, device=device) if need_gx else None
-        # dL/dx from 2 co + 1 floats per pixel where the layer allows it (same-size convolution on the matrix-core
-        # kernel), instead of the (F, M) feature gradients and their fold
-        dx_elems = 0 if (gx is None or x32 or not _QCONV_DX) else lib.qiddm_qconv_train_dx_elems(n_qubits, b, c, h, w, kh, kw, ph, pw,
-                                                                                c_out, co)
-        if dx_elems > 0:
-            wpix = torch.empty(dx_elems, dtype=torch.float32, device=device)
-            _capi.check(lib.qiddm_qconv_train_backward_dx(n_qubits, xx.data_ptr(), b, c, h, w, kh, kw, ph, pw,
-                                                          gy.data_ptr(), c_out, rt.data_ptr(), co, wpix.data_ptr(),
-                                                          hpart.data_ptr(), gx.data_ptr(), st))
-        else:
-            gfeat_t = torch.empty(f, b * ho * wo, dtype=torch.float32, device=device)
-            entry = lib.qiddm_qconv_train_backward_x32 if x32 else lib.qiddm_qconv_train_backward
-            _capi.check(entry(n_qubits, xx.data_ptr(), b, c, h, w, kh, kw, ph, pw, gy.data_ptr(), c_out, rt.data_ptr(),
-                              co, gfeat_t.data_ptr(), hpart.data_ptr(), 0 if gx is None else gx.data_ptr(), st))
-        ga = _angle_grads_off_stream(hpart, n_part, angles, n_qubits, f, c_out, co, device) \
-            if ctx.needs_input_grad[1] else None
-        return (None if gx is None else gx.to(x.dtype)), ga, None, None, None, None
+        gx, ga = _qconv_unitary_backward(x, angles, u, ctx.cfg, grad_y, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return gx, ga, None, None, None, None
+
+
+def _qconv_unitary_backward(x, angles, u, cfg, grad_y, need_gx, need_ga, bn=None):
+    """Backward of the unitary-route QConv2d: (dL/dx or None, dL/dangles or None).  ``bn = (conv_y, coef)``: grad_y is the
+    gradient BEHIND the training-mode BatchNorm2d that follows the layer, and dL/dy is formed per channel as
+    ``coef[0] * grad_y + coef[1] * conv_y + coef[2]`` inside the thin-product kernel (``qiddm_qconv_train_backward_bn``)."""
+    n_qubits, c_out, (kh, kw), (ph, pw) = cfg
+    device = x.device
+    b, c, h, w = x.shape
+    f = c * kh * kw
+    ho, wo = h + 2 * ph - kh + 1, w + 2 * pw - kw + 1
+    if qconv_unitary_route(n_qubits, c, (kh, kw), c_out) == "gemm":
+        if bn is not None:      # library-GEMM route: apply the BatchNorm coefficients with torch
+            conv_y, coef = bn
+            shape = (1, c_out, 1, 1)
+            grad_y = coef[0].view(shape) * grad_y + coef[1].view(shape) * conv_y + coef[2].view(shape)
+        hpart, gx = _qconv_unitary_backward_gemm(x, grad_y, u, n_qubits, c_out, (kh, kw), (ph, pw), need_gx)
+        ga = _angle_grads_off_stream(hpart, 1, angles, n_qubits, f, c_out, c_out, device) if need_ga else None
+        return (None if gx is None else gx.to(x.dtype)), ga
+    co = _row_channels(c_out)
+    lib = _capi.lib()
+    st = _stream_ptr(device)
+    rt = _unitary_rows(u, n_qubits, f, c_out, co, device)
+    # the matrix-core kernel converts every patch element to float32 anyway: hand it a float32 copy (one elementwise
+    # pass; its gather then holds half the bytes in flight)
+    x32 = bn is None and _QCONV_X32 and bool(lib.qiddm_qconv_train_x32_ok(b, c, h, w, kh, kw, ph, pw, c_out, co))
+    xx = x.detach().to(device=device, dtype=torch.float32).contiguous() if x32 else _as_f64(x, device).contiguous()
+    gy = _as_f64(grad_y, device).contiguous()
+    n_part = lib.qiddm_qconv_train_partials(b, ho, wo, f)
+    hpart = torch.empty(n_part, 2 * co, f + 1, dtype=torch.float32, device=device)
+    gx = torch.empty(b, c, h, w, dtype=torch.float64, device=device) if need_gx else None
+    # dL/dx from 2 co + 1 floats per pixel where the layer allows it (same-size convolution on the matrix-core
+    # kernel), instead of the (F, M) feature gradients and their fold
+    dx_elems = 0 if (gx is None or x32 or not _QCONV_DX) else \
+        lib.qiddm_qconv_train_dx_elems(n_qubits, b, c, h, w, kh, kw, ph, pw, c_out, co)
+    wpix = torch.empty(dx_elems, dtype=torch.float32, device=device) if dx_elems > 0 else None
+    gfeat_t = torch.empty(f, b * ho * wo, dtype=torch.float32, device=device) if wpix is None else None
+
+    def ptr(t):
+        return 0 if t is None else t.data_ptr()
+
+    if bn is not None:
+        conv_y, coef = bn
+        _capi.check(lib.qiddm_qconv_train_backward_bn(n_qubits, xx.data_ptr(), b, c, h, w, kh, kw, ph, pw, gy.data_ptr(),
+                                                      conv_y.data_ptr(), coef.data_ptr(), c_out, rt.data_ptr(), co,
+                                                      ptr(gfeat_t), ptr(wpix), hpart.data_ptr(), ptr(gx), st))
+    elif wpix is not None:
+        _capi.check(lib.qiddm_qconv_train_backward_dx(n_qubits, xx.data_ptr(), b, c, h, w, kh, kw, ph, pw,
+                                                      gy.data_ptr(), c_out, rt.data_ptr(), co, wpix.data_ptr(),
+                                                      hpart.data_ptr(), gx.data_ptr(), st))
+    else:
+        entry = lib.qiddm_qconv_train_backward_x32 if x32 else lib.qiddm_qconv_train_backward
+        _capi.check(entry(n_qubits, xx.data_ptr(), b, c, h, w, kh, kw, ph, pw, gy.data_ptr(), c_out, rt.data_ptr(),
+                          co, gfeat_t.data_ptr(), hpart.data_ptr(), ptr(gx), st))
+    ga = _angle_grads_off_stream(hpart, n_part, angles, n_qubits, f, c_out, co, device) if need_ga else None
+    return (None if gx is None else gx.to(x.dtype)), ga
 
 
 def qconv_unitary_execute(x: torch.Tensor, angles: torch.Tensor, n_qubits: int, out_channels: int, kernel_size,
@@ -1009,6 +1030,82 @@ def batch_norm_train(bn: torch.nn.BatchNorm2d, x: torch.Tensor) -> torch.Tensor:
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     return _BatchNormTrainFunction.apply(x, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps)
+
+
+class _QConvBNTrainFunction(torch.autograd.Function):
+    """``[QConv2d, BatchNorm2d]`` in training mode as ONE autograd node (every ``net`` of unet_simple, reference
+    nn/unet_simple.py:9-18): the forward is the two layers' own launches; the backward runs the BatchNorm statistics
+    pass only (``qiddm_batchnorm_backward_stats``) and lets the convolution's thin-product kernel apply the per-channel
+    coefficients while it loads its dL/dy -- the BatchNorm backward's transform pass (two tensors read, one written) and
+    the intermediate gradient tensor are gone.  The convolution's output never leaves the node, so nothing else can
+    depend on its gradient."""
+
+    @staticmethod
+    def forward(ctx, x, angles, bn_weight, bn_bias, running_mean, running_var, momentum, eps, n_qubits, out_channels,
+                kernel_size, padding):
+        u = circuit_unitary(angles.detach(), n_qubits, "CNOT")
+        y = qconv_unitary_forward(x, u, n_qubits, out_channels, kernel_size, padding)
+        b, c = y.shape[:2]
+        hw = y.numel() // max(b * c, 1)
+        out = torch.empty_like(y)
+        mean = torch.empty(c, dtype=torch.float64, device=y.device)
+        invstd = torch.empty_like(mean)
+        ws = _norm_workspace(b, c, hw, y.device)
+
+        def ptr(t):
+            return 0 if t is None else t.data_ptr()
+
+        _capi.check(_capi.lib().qiddm_batchnorm_train_forward(
+            y.data_ptr(), b, c, hw, ptr(bn_weight), ptr(bn_bias), ptr(running_mean), ptr(running_var), float(momentum),
+            float(eps), out.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(),
+            _stream_ptr(y.device)))
+        ctx.save_for_backward(x, angles, u, y, bn_weight, mean, invstd)
+        ctx.cfg = (n_qubits, out_channels, kernel_size, padding)
+        ctx.has_bias = bn_bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, angles, u, y, bn_weight, mean, invstd = ctx.saved_tensors
+        b, c = y.shape[:2]
+        hw = y.numel() // max(b * c, 1)
+        device = y.device
+        g = _as_f64(g, device).contiguous()
+        gw = torch.empty(c, dtype=torch.float64, device=device) if bn_weight is not None else None
+        gb = torch.empty(c, dtype=torch.float64, device=device) if ctx.has_bias else None
+        coef = torch.empty(3, c, dtype=torch.float64, device=device)
+        ws = _norm_workspace(b, c, hw, device)
+
+        def ptr(t):
+            return 0 if t is None else t.data_ptr()
+
+        _capi.check(_capi.lib().qiddm_batchnorm_backward_stats(
+            y.data_ptr(), g.data_ptr(), b, c, hw, ptr(bn_weight), mean.data_ptr(), invstd.data_ptr(), ptr(gw), ptr(gb),
+            coef.data_ptr(), ws.data_ptr(), ws.numel(), _stream_ptr(device)))
+        gx, ga = _qconv_unitary_backward(x, angles, u, ctx.cfg, g, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                         bn=(y, coef))
+        return (gx, ga, gw, gb) + (None,) * 8
+
+
+def batch_norm_eligible(bn: torch.nn.BatchNorm2d, channels: int) -> bool:
+    """Whether a float64 training-mode ``BatchNorm2d`` runs on the HIP kernels (the module-side half of
+    ``batch_norm_train``'s test)."""
+    return bool(type(bn) is torch.nn.BatchNorm2d and bn.training and bn.momentum is not None
+                and bn.num_features == channels
+                and (bn.weight is None or bn.weight.dtype == torch.float64)
+                and (bn.running_mean is None or bn.running_mean.dtype == torch.float64))
+
+
+def qconv_bn_train(x: torch.Tensor, angles: torch.Tensor, bn: torch.nn.BatchNorm2d, n_qubits: int, out_channels: int,
+                   kernel_size, padding) -> torch.Tensor:
+    """``bn(QConv2d(x))`` through the circuit unitary with the BatchNorm backward folded into the convolution's
+    (``_QConvBNTrainFunction``).  The caller has checked ``qconv_unitary_trainable`` and ``batch_norm_eligible``."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    return _QConvBNTrainFunction.apply(x, angles, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, n_qubits,
+                                       out_channels, tuple(kernel_size), tuple(padding))
 
 
 class _Upsample2xFunction(torch.autograd.Function):

@@ -241,6 +241,34 @@ __global__ __launch_bounds__(kNormThreads) void bn_back_apply_kernel(const doubl
   }
 }
 
+// backward pass 2 without the transform: dweight, dbias and the three per-channel coefficients with which a consumer
+// forms dL/dx itself,  dx = coef[0][c] gy + coef[1][c] x + coef[2][c]  (the same  weight * invstd * (g - mean(g) -
+// xhat * mean(g * xhat))  multiplied out) -- the quantum convolution in front of the BatchNorm applies it while it loads
+// its dL/dy (qsim_qconv_train.h: TrainConv::bn_coef)
+__global__ __launch_bounds__(64) void bn_back_coef_kernel(const NormGeom g, const double* __restrict__ partial,
+                                                          const double* __restrict__ weight,
+                                                          const double* __restrict__ save_mean,
+                                                          const double* __restrict__ save_invstd,
+                                                          double* __restrict__ gweight, double* __restrict__ gbias,
+                                                          double* __restrict__ coef) {
+  for (int c = threadIdx.x; c < g.channels; c += 64) {
+    double sg = 0, sgx = 0;
+    for (int i = 0; i < g.slices; ++i) {
+      sg += partial[((int64_t)c * g.slices + i) * 2 + 0];
+      sgx += partial[((int64_t)c * g.slices + i) * 2 + 1];
+    }
+    if (gweight) gweight[c] = sgx;
+    if (gbias) gbias[c] = sg;
+    const double n = (double)(g.batch * g.hw);
+    const double mean = save_mean[c], invstd = save_invstd[c];
+    const double k = invstd * (weight ? weight[c] : 1.0);
+    const double mg = sg / n, mgx = sgx / n;
+    coef[c] = k;
+    coef[g.channels + c] = -k * invstd * mgx;
+    coef[2 * g.channels + c] = k * (invstd * mgx * mean - mg);
+  }
+}
+
 // ---- bilinear x2 (the `Upsample(scale_factor=2, mode="bilinear")` in front of every `up_conv`, reference
 // nn/unet_simple.py:40-49) with the interpolation weights handed in as the two dense 1-D matrices ah (2H x H) and
 // aw (2W x W) -- the caller takes them from torch's own operator, so the numbers are torch's; row o of such a matrix
@@ -497,6 +525,27 @@ int qiddm_batchnorm_backward(const double* x, const double* grad_y, int64_t batc
   hipLaunchKernelGGL(qiddm::bn_back_apply_kernel, grid, dim3(qiddm::kNormThreads), 0, st, x, grad_y, g, partial,
                      weight, save_mean, save_invstd, grad_x, grad_weight, grad_bias);
   return launched("bn_back_apply_kernel");
+}
+
+int qiddm_batchnorm_backward_stats(const double* x, const double* grad_y, int64_t batch, int64_t channels, int64_t hw,
+                                   const double* weight, const double* save_mean, const double* save_invstd,
+                                   double* grad_weight, double* grad_bias, double* coef, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+  qiddm::NormGeom g;
+  const int rc = make_geom(batch, channels, hw, &g);
+  if (rc != QIDDM_OK) return rc;
+  if (!x || !grad_y || !save_mean || !save_invstd || !coef || !workspace)
+    return fail(QIDDM_ERR_INVALID, "x/grad_y/save_mean/save_invstd/coef/workspace is NULL");
+  if (workspace_bytes < qiddm_batchnorm_workspace_bytes(batch, channels, hw))
+    return fail(QIDDM_ERR_INVALID, "workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  double* partial = static_cast<double*>(workspace);
+  const dim3 grid((unsigned)g.channels, (unsigned)g.slices);
+  hipLaunchKernelGGL(qiddm::bn_back_stats_kernel, grid, dim3(qiddm::kNormThreads), 0, st, x, grad_y, g, save_mean,
+                     save_invstd, partial);
+  hipLaunchKernelGGL(qiddm::bn_back_coef_kernel, dim3(1), dim3(64), 0, st, g, partial, weight, save_mean, save_invstd,
+                     grad_weight, grad_bias, coef);
+  return launched("bn_back_coef_kernel");
 }
 
 int qiddm_upsample2x_forward(const double* x, int64_t planes, int64_t height, int64_t width, const double* ah,

@@ -318,7 +318,8 @@ bool train_fits32(int64_t batch, int64_t in_channels, int64_t height, int64_t wi
 int train_backward(int32_t n_qubits, const void* x, bool x32, int64_t batch, int64_t in_channels, int64_t height,
                    int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, const double* grad_y,
                    int64_t out_channels, const float* rows, int32_t row_channels, float* grad_features_t,
-                   float* pixel_rows, float* h_partials, double* grad_x, void* stream);
+                   float* pixel_rows, float* h_partials, double* grad_x, void* stream, const double* bn_y = nullptr,
+                   const double* bn_coef = nullptr);
 
 // dL/dx from per-pixel rows (qsim_qconv_dx.h) instead of feature gradients + fold: the matrix-core kernel, a same-size
 // convolution, at most 32 input channels, LDS of the dx kernel within the limit.  QIDDM_QCONV_FOLD=1 switches it off.
@@ -332,16 +333,29 @@ DxChoice train_dx_choice(const qiddm::TrainConv& tc, int32_t row_channels, bool 
   if (env_fold || !mfma || tc.Ho != tc.H || tc.Wo != tc.W || tc.C > 32 || tc.kh * tc.kw > 32) return ch;
   size_t smem = 0;
   const void* kern = nullptr;
-  if (row_channels == 8) {
-    smem = qiddm::dx_lds_bytes<16>(tc);
-    kern = reinterpret_cast<const void*>(qiddm::qconv_dx_kernel<16>);
-  } else if (row_channels == 16) {
-    smem = qiddm::dx_lds_bytes<32>(tc);
-    kern = reinterpret_cast<const void*>(qiddm::qconv_dx_kernel<32>);
-  } else if (row_channels == 32) {
-    smem = qiddm::dx_lds_bytes<64>(tc);
-    kern = reinterpret_cast<const void*>(qiddm::qconv_dx_kernel<64>);
-  }
+  const bool one = tc.C <= 16;   // one block of 16 input channels, or two
+  // float4 of a tile's source rows per thread (the kernel prefetches 2, 4 or 6 of them a tile ahead)
+  const int64_t k2 = 2 * (int64_t)row_channels;
+  const int64_t slots = ((qiddm::kDxTile + 2 * qiddm::dx_halo(tc)) * (k2 / 4) + qiddm::kDxThreads - 1) / qiddm::kDxThreads;
+#define QIDDM_DX_PICK(K2)                                                                                         \
+  do {                                                                                                            \
+    smem = qiddm::dx_lds_bytes<K2>(tc);                                                                           \
+    if (one)                                                                                                      \
+      kern = slots <= 2 ? reinterpret_cast<const void*>(qiddm::qconv_dx_kernel<K2, 1, 2>)                          \
+                        : (slots <= 4 ? reinterpret_cast<const void*>(qiddm::qconv_dx_kernel<K2, 1, 4>)            \
+                                      : reinterpret_cast<const void*>(qiddm::qconv_dx_kernel<K2, 1, 6>));          \
+    else                                                                                                          \
+      kern = slots <= 2 ? reinterpret_cast<const void*>(qiddm::qconv_dx_kernel<K2, 2, 2>)                          \
+                        : (slots <= 4 ? reinterpret_cast<const void*>(qiddm::qconv_dx_kernel<K2, 2, 4>)            \
+                                      : reinterpret_cast<const void*>(qiddm::qconv_dx_kernel<K2, 2, 6>));          \
+  } while (0)
+  if (row_channels == 8)
+    QIDDM_DX_PICK(16);
+  else if (row_channels == 16)
+    QIDDM_DX_PICK(32);
+  else if (row_channels == 32)
+    QIDDM_DX_PICK(64);
+#undef QIDDM_DX_PICK
   if (kern && smem <= kMaxLds / 2) {   // (two or more workgroups per CU)
     ch.kern = kern;
     ch.smem = smem;
@@ -387,6 +401,21 @@ int64_t qiddm_qconv_train_dx_elems(int32_t n_qubits, int64_t batch, int64_t in_c
                                       false, kh, kw, in_channels).kern != nullptr;
   if (!train_dx_choice(tc, row_channels, mfma).kern) return 0;
   return tc.M * (2 * (int64_t)row_channels + 1);
+}
+
+int qiddm_qconv_train_backward_bn(int32_t n_qubits, const double* x, int64_t batch, int64_t in_channels, int64_t height,
+                                  int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
+                                  const double* grad_out, const double* conv_y, const double* bn_coef,
+                                  int64_t out_channels, const float* rows, int32_t row_channels,
+                                  float* grad_features_t, float* pixel_rows, float* h_partials, double* grad_x,
+                                  void* stream) {
+  if (!conv_y || !bn_coef) return fail(QIDDM_ERR_INVALID, "conv_y/bn_coef is NULL");
+  if (pixel_rows && (!grad_x || qiddm_qconv_train_dx_elems(n_qubits, batch, in_channels, height, width, kh, kw, pad_h,
+                                                            pad_w, out_channels, row_channels) <= 0))
+    return fail(QIDDM_ERR_UNSUPPORTED, "pixel_rows: this layer keeps the feature-gradient route");
+  return train_backward(n_qubits, x, false, batch, in_channels, height, width, kh, kw, pad_h, pad_w, grad_out,
+                        out_channels, rows, row_channels, pixel_rows ? nullptr : grad_features_t, pixel_rows, h_partials,
+                        grad_x, stream, conv_y, bn_coef);
 }
 
 int qiddm_qconv_train_backward_dx(int32_t n_qubits, const double* x, int64_t batch, int64_t in_channels, int64_t height,
@@ -437,7 +466,9 @@ namespace {
 int train_backward(int32_t n_qubits, const void* x, bool x32, int64_t batch, int64_t in_channels, int64_t height,
                    int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, const double* grad_y,
                    int64_t out_channels, const float* rows, int32_t row_channels, float* grad_features_t,
-                   float* pixel_rows, float* h_partials, double* grad_x, void* stream) {
+                   float* pixel_rows, float* h_partials, double* grad_x, void* stream, const double* bn_y,
+                   const double* bn_coef) {
+  if ((bn_y == nullptr) != (bn_coef == nullptr)) return fail(QIDDM_ERR_INVALID, "bn_y and bn_coef go together");
   if (n_qubits < 1 || n_qubits > 12) return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d outside 1..12", n_qubits);
   if (batch < 1 || in_channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad_h < 0 || pad_w < 0 ||
       out_channels < 1)
@@ -456,6 +487,8 @@ int train_backward(int32_t n_qubits, const void* x, bool x32, int64_t batch, int
   const int jch = (int)((f + 1 + qiddm::kTcThreads - 1) / qiddm::kTcThreads);
   qiddm::TrainConv tc = train_geometry(n_qubits, batch, in_channels, height, width, kh, kw, pad_h, pad_w, out_channels);
   tc.groups = train_groups(f);
+  tc.bn_y = bn_y;
+  tc.bn_coef = bn_coef;
   tc.stamps = qiddm_capi::stamp_buffer(8);
   const unsigned grid = (unsigned)train_grid(batch * ho * wo, f);
   hipStream_t st = static_cast<hipStream_t>(stream);

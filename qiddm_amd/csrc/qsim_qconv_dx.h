@@ -44,19 +44,22 @@ __host__ __device__ inline size_t dx_lds_bytes(const TrainConv& tc) {
 
 using dx_f32x4 = float __attribute__((ext_vector_type(4)));
 
-constexpr int kDxPrefetch = 6;   // float4 per thread of the next tile's source rows held in registers
+constexpr int kDxPrefetch = 6;   // most float4 per thread of the next tile's source rows held in registers
 constexpr int kDxMaxC = 32;
 
 // Per tile the kernel has two global streams -- the source rows (contiguous in wpix) and x / gx -- and three barriers.
 // Both streams are issued a phase ahead: the NEXT tile's source rows go into registers right after this tile's were
 // written to LDS, this tile's x values at the top of the tile; what is left on the critical path is LDS and the MFMAs.
-template <int K2>
+// CB: 16-channel blocks compiled in (1: C <= 16, 2: C <= 32) -- sizes the accumulators and the x / gx slots of a thread
+// PF: float4 per thread of the next tile's source rows held in registers (2, 4 or 6: the host picks the smallest that
+//     covers 64 + 2 halo rows; more rows than that are fetched when the tile starts)
+template <int K2, int CB, int PF>
 __global__ __launch_bounds__(kDxThreads) void qconv_dx_kernel(const double* __restrict__ x, const float* __restrict__ wpix,
                                                                const float* __restrict__ rt, double* __restrict__ gx,
                                                                const TrainConv tc) {
   constexpr int SS = K2 + 1, K4 = K2 / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const int KK = tc.kh * tc.kw, C = tc.C, CP = dx_cpad(C), NB = (C + 15) / 16;
+  const int KK = tc.kh * tc.kw, C = tc.C, CP = dx_cpad(C);
   const int halo = dx_halo(tc), n_src = kDxTile + 2 * halo;
   float* s_src = reinterpret_cast<float*>(smem_raw);        // [n_src][SS]: 2 W3 of source pixel tile_start - halo + r
   float* s_k = s_src + (size_t)n_src * SS;                   // [n_src]
@@ -83,12 +86,12 @@ __global__ __launch_bounds__(kDxThreads) void qconv_dx_kernel(const double* __re
 
   const int64_t tiles = (total + kDxTile - 1) / kDxTile;
   const int n4 = n_src * K4;   // float4 elements of a tile's source rows
-  dx_f32x4 pre[kDxPrefetch];
+  dx_f32x4 pre[PF];
   float pre_k = 0.f;
   auto issue_rows = [&](int64_t tile) {
     const int64_t first = tile * kDxTile - halo;
 #pragma unroll
-    for (int u = 0; u < kDxPrefetch; ++u) {
+    for (int u = 0; u < PF; ++u) {
       const int i = tid + u * kDxThreads;
       const int64_t m = first + i / K4;
       pre[u] = dx_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -105,10 +108,11 @@ __global__ __launch_bounds__(kDxThreads) void qconv_dx_kernel(const double* __re
     const int64_t b0 = p0 / hw;
     const uint32_t rem0 = (uint32_t)(p0 - b0 * hw);
     // ---- this tile's x values: thread = (channel, pixel), pixels fastest (512-byte rows of x and gx) ------------------
-    double xv[kDxMaxC / 4];
-    int64_t xe[kDxMaxC / 4];
+    constexpr int XS = 4 * CB;   // (channel, pixel) slots of a thread: 16 CB channels x 64 pixels / 256 threads
+    double xv[XS];
+    int64_t xe[XS];
 #pragma unroll
-    for (int u = 0; u < kDxMaxC / 4; ++u) {
+    for (int u = 0; u < XS; ++u) {
       const int i = tid + u * kDxThreads;
       const int c = i >> 6, pl = i & 63;
       xe[u] = -1;
@@ -123,7 +127,7 @@ __global__ __launch_bounds__(kDxThreads) void qconv_dx_kernel(const double* __re
     // ---- source rows [p0 - halo, p0 + 64 + halo) from the registers (zero outside [0, M)) ---------------------------
     {
 #pragma unroll
-      for (int u = 0; u < kDxPrefetch; ++u) {
+      for (int u = 0; u < PF; ++u) {
         const int i = tid + u * kDxThreads;
         if (i < n4) {
           float* dst = s_src + (size_t)(i / K4) * SS + 4 * (i % K4);
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(kDxThreads) void qconv_dx_kernel(const double* __re
       if (tid < n_src) s_k[tid] = pre_k;
       // wide images: what the registers do not hold
       const int64_t first = p0 - halo;
-      for (int i = tid + kDxPrefetch * kDxThreads; i < n4; i += kDxThreads) {
+      for (int i = tid + PF * kDxThreads; i < n4; i += kDxThreads) {
         const int64_t m = first + i / K4;
         dx_f32x4 v{0.f, 0.f, 0.f, 0.f};
         if (m >= 0 && m < total) v = wpix4[(size_t)m * K4 + (i % K4)];
@@ -180,7 +184,9 @@ __global__ __launch_bounds__(kDxThreads) void qconv_dx_kernel(const double* __re
     }
     // ---- the product: wave q owns input pixels 16 q .. 16 q + 15, all channels ---------------------------------------
     {
-      dx_f32x4 acc[2] = {dx_f32x4{0.f, 0.f, 0.f, 0.f}, dx_f32x4{0.f, 0.f, 0.f, 0.f}};
+      dx_f32x4 acc[CB];
+#pragma unroll
+      for (int nb = 0; nb < CB; ++nb) acc[nb] = dx_f32x4{0.f, 0.f, 0.f, 0.f};
       const uint32_t mask = s_mask[16 * q + l15];
       const int row0 = 16 * q + l15 + halo;
       const int second = CP == 16 ? 0 : (dx_bcol(l4, 16 + l15, CP) - dx_bcol(l4, l15, CP));
@@ -195,13 +201,13 @@ __global__ __launch_bounds__(kDxThreads) void qconv_dx_kernel(const double* __re
           for (int s4 = 0; s4 < K4; ++s4) {
             a[s4] = arow[4 * s4];
             b0v[s4] = brow[(size_t)4 * s4 * CP];
-            b1v[s4] = NB > 1 ? brow[(size_t)4 * s4 * CP + second] : 0.f;
+            b1v[s4] = CB > 1 ? brow[(size_t)4 * s4 * CP + second] : 0.f;
           }
 #pragma unroll
           for (int s4 = 0; s4 < K4; ++s4) {
             const float av = ok ? a[s4] : 0.f;
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0v[s4], acc[0], 0, 0, 0);
-            if (NB > 1) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1v[s4], acc[1], 0, 0, 0);
+            if constexpr (CB > 1) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1v[s4], acc[1], 0, 0, 0);
           }
         }
       }
@@ -209,13 +215,13 @@ __global__ __launch_bounds__(kDxThreads) void qconv_dx_kernel(const double* __re
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         s_out[(size_t)l15 * (kDxTile + 1) + 16 * q + 4 * l4 + r] = acc[0][r];
-        if (NB > 1) s_out[(size_t)(16 + l15) * (kDxTile + 1) + 16 * q + 4 * l4 + r] = acc[1][r];
+        if constexpr (CB > 1) s_out[(size_t)(16 + l15) * (kDxTile + 1) + 16 * q + 4 * l4 + r] = acc[1][r];
       }
     }
     __syncthreads();
     // ---- out ---------------------------------------------------------------------------------------------------------
 #pragma unroll
-    for (int u = 0; u < kDxMaxC / 4; ++u) {
+    for (int u = 0; u < XS; ++u) {
       const int i = tid + u * kDxThreads;
       const int c = i >> 6, pl = i & 63;
       if (xe[u] >= 0) {

@@ -32,6 +32,12 @@ struct TrainConv {
   float pad_norm2;    // 0.25 * (D - F)
   float post_scale;   // D / 2
   unsigned long long* stamps;  // diagnostics (QIDDM_STAMP_PTR): per-phase s_memtime sums of workgroup 0, else null
+  // dL/dy handed in BEFORE the BatchNorm2d that follows the convolution (training mode): with bn_y = the convolution's
+  // own output and bn_coef = [3][C_out] (qiddm_batchnorm_backward_stats), the kernels form
+  //     dL/dy = coef[0][c] * grad_y + coef[1][c] * bn_y + coef[2][c]
+  // while they load it -- the BatchNorm backward's transform pass (read 2, write 1 tensor) is never run.  Null: grad_y as is.
+  const double* bn_y;
+  const double* bn_coef;
   float* wpix;        // matrix-core kernel: per-pixel rows [M][2 CO] of 2 W2 / |v|, then [M] of dot / |v|^2, INSTEAD of
                       // gfeat_t (qsim_qconv_dx.h turns them into dL/dx); null: feature gradients + fold
 };
@@ -149,7 +155,13 @@ __global__ __launch_bounds__(kTcThreads, 1) void qconv_train_backward_kernel(con
         const float ar = (mine[i] + rp[c]) * inv, ai = (mine[CQ + i] + rp[CO + c]) * inv;
         const float p2 = ar * ar + ai * ai;
         float t = 0.f;
-        if (valid && c < tc.C_out && p2 * tc.post_scale <= 1.0f) t = (float)gpix[(size_t)c * pixels] * tc.post_scale;
+        if (valid && c < tc.C_out && p2 * tc.post_scale <= 1.0f) {
+          double g = gpix[(size_t)c * pixels];
+          if (tc.bn_y)
+            g = fma(tc.bn_coef[c], g, fma(tc.bn_coef[tc.C_out + c], tc.bn_y[(size_t)b * tc.C_out * pixels + pix + (size_t)c * pixels],
+                                          tc.bn_coef[2 * tc.C_out + c]));
+          t = (float)g * tc.post_scale;
+        }
         dotp = fmaf(2.0f * t, p2, dotp);
         s_w[lane * WS + c] = t * ar;
         s_w[lane * WS + CO + c] = t * ai;

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
   constexpr int GC = CO / kTmWaves;
   static_assert(PRE <= 64, "one in-image bit per prefetched column in a 64-bit mask");
   XT raw[PRE];
-  double graw[GC];
+  double graw[GC], yraw[GC];   // dL/dy of the tile in flight (and, in front of a BatchNorm, the convolution's own output)
   uint64_t inb_mask = 0;
   uint32_t glive_mask = 0;
   int g_i0 = 0, g_j0 = 0;
@@ -167,7 +167,11 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
       const bool live = valid && c < tc.C_out;
       glive_mask |= (uint32_t)live << cu;
       graw[cu] = 0.0;
-      if (c < tc.C_out) graw[cu] = gy[gpix + (uint32_t)c * (uint32_t)pixels];   // wave-uniform; tail pixels read pixel M - 1
+      yraw[cu] = 0.0;
+      if (c < tc.C_out) {   // wave-uniform; tail pixels read pixel M - 1
+        graw[cu] = gy[gpix + (uint32_t)c * (uint32_t)pixels];
+        if (tc.bn_y) yraw[cu] = tc.bn_y[gpix + (uint32_t)c * (uint32_t)pixels];
+      }
     }
     inb_mask = 0;
     g_base = (uint32_t)((int64_t)b * tc.C * tc.H * tc.W);
@@ -291,8 +295,14 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
       if (q == 0) s_v[lane * FS + F] = 0.5f;
       s_n2[q * kTmTile + lane] = n2;
 #pragma unroll
-      for (int cu = 0; cu < GC; ++cu)
-        s_t[lane * TS + q + kTmWaves * cu] = ((glive_mask >> cu) & 1) ? (float)graw[cu] * tc.post_scale : 0.f;
+      for (int cu = 0; cu < GC; ++cu) {
+        double g = graw[cu];
+        if (tc.bn_y) {   // through the BatchNorm behind the convolution: three per-channel coefficients (scalar loads)
+          const int c = q + kTmWaves * cu < tc.C_out ? q + kTmWaves * cu : 0;
+          g = fma(tc.bn_coef[c], g, fma(tc.bn_coef[tc.C_out + c], yraw[cu], tc.bn_coef[2 * tc.C_out + c]));
+        }
+        s_t[lane * TS + q + kTmWaves * cu] = ((glive_mask >> cu) & 1) ? (float)g * tc.post_scale : 0.f;
+      }
     }
     __syncthreads();
     mark(0);

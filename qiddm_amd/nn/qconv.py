@@ -96,6 +96,19 @@ class QConv2d(torch.nn.Module):
         y = self._post_process(self.qnode(feats))                        # ((b h w), C_out)
         return y.reshape(b, h_out, w_out, -1).permute(0, 3, 1, 2).contiguous()
 
+    def train_forward_bn(self, x, bn):
+        """``bn(self(x))`` as one autograd node when this layer trains through its circuit unitary and ``bn`` is a float64
+        training-mode BatchNorm2d on the device (``circuit.qconv_bn_train``: the BatchNorm backward's transform pass is
+        folded into the convolution's backward); None otherwise -- the caller then runs the two modules."""
+        if not (torch.is_grad_enabled() and self.qnode is self._own_qnode and x.is_cuda and x.dim() == 4
+                and x.numel() > 0 and x.shape[1] == self.in_channels and _c._default_precision == "f32"
+                and _c._QCONV_BN_FUSED
+                and _c.qconv_unitary_trainable(self.wires, self.in_channels, self.kernel_size, self.out_channels)
+                and _c.batch_norm_eligible(bn, self.out_channels)):
+            return None
+        angles = _c.on_weight_grad_stream(lambda w: _qw_tanh(w.double()), self.weights)
+        return _c.qconv_bn_train(x.double(), angles, bn, self.wires, self.out_channels, self.kernel_size, self.padding)
+
     def eval_forward(self, x, upsample2x=False, batch_norm=None):
         """Inference through the cached unitary + GEMM with the layer's ``unet_simple`` neighbours folded in
         (``upsample2x``: the bilinear x2 in front of an ``up_conv``; ``batch_norm``: the eval-mode BatchNorm2d behind

@@ -28,8 +28,17 @@ def _conv3(c_in, c_out, k, qdepth):
 def _run(net: torch.nn.Sequential, x):
     """``net(x)`` with training-mode float64 BatchNorm2d layers on the HIP kernels (same numbers, same running
     statistics; torch's float64 batch norm is several generic launches per direction)."""
-    for m in net:
+    i = 0
+    while i < len(net):
+        m = net[i]
+        if isinstance(m, QConv2d) and i + 1 < len(net) and type(net[i + 1]) is torch.nn.BatchNorm2d:
+            # [QConv2d, BatchNorm2d] (unet_simple): one autograd node, the BatchNorm backward inside the convolution's
+            fused = m.train_forward_bn(x, net[i + 1])
+            if fused is not None:
+                x, i = fused, i + 2
+                continue
         x = _c.batch_norm_train(m, x) if type(m) is torch.nn.BatchNorm2d else m(x)
+        i += 1
     return x
 
 

@@ -278,3 +278,40 @@ def test_weight_gradient_side_stream_leaves_the_same_gradients(monkeypatch):
             assert torch.equal(a[k], b[k]), k
     for k in s1:
         assert torch.equal(s1[k], s0[k]), k
+
+
+@pytest.mark.parametrize("c_in,c_out,k,pad,hw", [(1, 8, 3, 1, (28, 28)), (16, 8, 3, 1, (28, 28)), (32, 16, 1, 0, (14, 14)),
+                                                  (16, 32, 3, 1, (7, 7)), (5, 3, 3, 0, (9, 8))])
+def test_qconv_batchnorm_pair_as_one_node_matches_the_two_modules(c_in, c_out, k, pad, hw, monkeypatch):
+    """[QConv2d, BatchNorm2d] in training mode as one autograd node (the BatchNorm backward's transform folded into the
+    convolution's thin-product kernel) against the two modules run one after the other: same output, running statistics
+    and gradients of the input, the circuit weights and the BatchNorm affine pair.  Shapes: the VALU kernel (first layer
+    of unet_simple), the matrix-core kernel with and without the per-pixel-row dL/dx, and a layer without padding."""
+    from qiddm_amd import circuit, nn
+    from qiddm_amd.nn.unet import _run
+
+    def run(fused):
+        monkeypatch.setattr(circuit, "_QCONV_BN_FUSED", fused)
+        torch.manual_seed(17)
+        net = torch.nn.Sequential(nn.QConv2d(c_in, c_out, k, pad, 2), torch.nn.BatchNorm2d(c_out)).to("cuda", torch.double).train()
+        with torch.no_grad():
+            net[1].weight.uniform_(0.5, 1.5)
+            net[1].bias.uniform_(-0.5, 0.5)
+        x = torch.rand(4, c_in, *hw, dtype=torch.double, device="cuda").requires_grad_(True)
+        out = _run(net, x)
+        g = torch.randn(out.shape, dtype=torch.double, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+        (out * g).sum().backward()
+        return out.detach(), x.grad, {n: p.grad for n, p in net.named_parameters()}, \
+            {n: b.clone() for n, b in net.named_buffers()}, type(out.grad_fn).__name__
+
+    out1, gx1, gp1, buf1, node1 = run(True)
+    out0, gx0, gp0, buf0, node0 = run(False)
+    assert node1 == "_QConvBNTrainFunctionBackward" and node0 == "_BatchNormTrainFunctionBackward"
+    assert torch.equal(out1, out0)
+    for n in buf1:
+        assert torch.equal(buf1[n], buf0[n]), n
+    scale = max(1.0, gx0.abs().max().item())
+    assert torch.allclose(gx1, gx0, rtol=0, atol=1e-5 * scale), (gx1 - gx0).abs().max()
+    for n in gp1:
+        s = max(1.0, gp0[n].abs().max().item())
+        assert torch.allclose(gp1[n], gp0[n], rtol=0, atol=1e-5 * s), (n, (gp1[n] - gp0[n]).abs().max())
