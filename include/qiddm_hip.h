@@ -505,7 +505,11 @@ int qiddm_qconv_train_backward_dx(int32_t n_qubits, const double *x, int64_t bat
  * bn_coef the (3, out_channels) coefficients of qiddm_batchnorm_backward_stats; the kernels form
  * dL/dy = coef[0] grad_out + coef[1] conv_y + coef[2] per channel while they load it, so the BatchNorm backward's
  * transform pass never runs.  With pixel_rows (qiddm_qconv_train_dx_elems() floats) dL/dx comes from the per-pixel
- * rows and grad_features_t may be NULL; otherwise as qiddm_qconv_train_backward.                                */
+ * rows and grad_features_t may be NULL; otherwise as qiddm_qconv_train_backward.  qiddm_qconv_train_bn_ok() says whether
+ * a layer has this form (1) or keeps the separate BatchNorm backward (0: the matrix-core kernel with 32 row channels has no
+ * registers left for it; qiddm_qconv_train_backward_bn then returns QIDDM_ERR_UNSUPPORTED).                       */
+int32_t qiddm_qconv_train_bn_ok(int64_t batch, int64_t in_channels, int64_t height, int64_t width, int64_t kh,
+                                int64_t kw, int64_t pad_h, int64_t pad_w, int64_t out_channels, int32_t row_channels);
 int qiddm_qconv_train_backward_bn(int32_t n_qubits, const double *x, int64_t batch, int64_t in_channels,
                                   int64_t height, int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
                                   const double *grad_out, const double *conv_y, const double *bn_coef,

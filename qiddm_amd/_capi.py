@@ -84,6 +84,7 @@ EXPORTS = (
     "qiddm_batchnorm_backward",
     "qiddm_batchnorm_backward_stats",
     "qiddm_qconv_train_backward_bn",
+    "qiddm_qconv_train_bn_ok",
     "qiddm_upsample2x_forward",
     "qiddm_upsample2x_backward",
     "qiddm_mixed_workspace_bytes",
@@ -217,6 +218,8 @@ def _declare(lib):
     lib.qiddm_batchnorm_train_forward.argtypes = [vp, i64, i64, i64, vp, vp, vp, vp, dbl, dbl, vp, vp, vp, vp, i64, vp]
     lib.qiddm_batchnorm_backward_stats.restype = ctypes.c_int
     lib.qiddm_batchnorm_backward_stats.argtypes = [vp, vp, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.qiddm_qconv_train_bn_ok.restype = ctypes.c_int32
+    lib.qiddm_qconv_train_bn_ok.argtypes = [i64, i64, i64, i64, i64, i64, i64, i64, i64, ctypes.c_int32]
     lib.qiddm_qconv_train_backward_bn.restype = ctypes.c_int
     lib.qiddm_qconv_train_backward_bn.argtypes = [ctypes.c_int32, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, vp, vp,
                                                   i64, vp, ctypes.c_int32, vp, vp, vp, vp, vp]

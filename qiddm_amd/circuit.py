@@ -1087,6 +1087,17 @@ class _QConvBNTrainFunction(torch.autograd.Function):
         return (gx, ga, gw, gb) + (None,) * 8
 
 
+def qconv_bn_foldable(x_shape, n_qubits: int, out_channels: int, kernel_size, padding) -> bool:
+    """Whether the unitary-route backward of this layer can apply a following BatchNorm's backward transform itself
+    (``qiddm_qconv_train_bn_ok``; the library-GEMM route of the widest layers does it with torch)."""
+    b, c, h, w = x_shape
+    (kh, kw), (ph, pw) = kernel_size, padding
+    route = qconv_unitary_route(n_qubits, c, (kh, kw), out_channels)
+    if route != "thin":
+        return route == "gemm"
+    return bool(_capi.lib().qiddm_qconv_train_bn_ok(b, c, h, w, kh, kw, ph, pw, out_channels, _row_channels(out_channels)))
+
+
 def batch_norm_eligible(bn: torch.nn.BatchNorm2d, channels: int) -> bool:
     """Whether a float64 training-mode ``BatchNorm2d`` runs on the HIP kernels (the module-side half of
     ``batch_norm_train``'s test)."""

@@ -264,7 +264,16 @@ struct TmChoice {
   const void* kern = nullptr;
   size_t smem = 0;
 };
-TmChoice train_mfma_choice(int64_t f, int32_t row_channels, bool fits32, bool x32, int64_t kh, int64_t kw, int64_t c_in) {
+// the BatchNorm-folding variant of a shape (8 / 16 row channels only: see the kernel's BN parameter); nullptr otherwise
+template <int CO, int J, int SK, int SC>
+const void* tm_bn_kernel() {
+  if constexpr (CO <= 16)
+    return reinterpret_cast<const void*>(qiddm::qconv_train_backward_mfma_kernel<CO, J, double, SK, SC, true>);
+  else
+    return nullptr;
+}
+TmChoice train_mfma_choice(int64_t f, int32_t row_channels, bool fits32, bool x32, int64_t kh, int64_t kw, int64_t c_in,
+                           bool bn = false) {
   // from 32 patch features on and whenever its LDS tiles fit; the VALU kernel keeps the narrowest layers (9 / 16
   // features: the whole backward of the layer measured 0.37 / 0.55 ms against 0.53 / 0.67 on the MFMA kernel at
   // 2560 x 28 x 28 pixels, tools/stamp_qconv_train.py; from 32 features on the MFMA kernel wins) and the widest.
@@ -277,19 +286,21 @@ TmChoice train_mfma_choice(int64_t f, int32_t row_channels, bool fits32, bool x3
   if (env_valu || !fits32 || (f < 32 && !env_mfma && !narrow_ok)) return ch;
   const int jbm = (int)((qiddm::tm_fcols((int)f) / 16 + qiddm::kTmWaves - 1) / qiddm::kTmWaves);
 #define QIDDM_TM_CASE(CO, J)                                                                                       \
-  if (!ch.kern && row_channels == CO && jbm <= J && qiddm::tm_lds_bytes<CO>((int)f) <= kMaxLds) {                   \
-    ch.smem = qiddm::tm_lds_bytes<CO>((int)f);                                                                     \
+  if (!ch.kern && row_channels == CO && jbm <= J && qiddm::tm_lds_bytes_bn<CO>((int)f) <= kMaxLds) {                   \
+    ch.smem = qiddm::tm_lds_bytes_bn<CO>((int)f);                                                                     \
     ch.kern = x32 ? reinterpret_cast<const void*>(qiddm::qconv_train_backward_mfma_kernel<CO, J, float>)           \
-                  : reinterpret_cast<const void*>(qiddm::qconv_train_backward_mfma_kernel<CO, J, double>);         \
+                  : (bn ? tm_bn_kernel<CO, J, 0, 0>()                                                              \
+                        : reinterpret_cast<const void*>(qiddm::qconv_train_backward_mfma_kernel<CO, J, double>));  \
   }
   // the layer shapes of unet_simple with kernel extent and channel count compiled in (no control flow in the gather)
   static const bool env_generic = std::getenv("QIDDM_QCONV_GENERIC") != nullptr;
 #define QIDDM_TM_SCASE(CO, J, SK, SC)                                                                              \
   if (!ch.kern && !env_generic && row_channels == CO && jbm <= J && kh == SK && kw == SK && c_in == SC &&          \
-      qiddm::tm_lds_bytes<CO>((int)f) <= kMaxLds) {                                                                \
-    ch.smem = qiddm::tm_lds_bytes<CO>((int)f);                                                                     \
+      qiddm::tm_lds_bytes_bn<CO>((int)f) <= kMaxLds) {                                                                \
+    ch.smem = qiddm::tm_lds_bytes_bn<CO>((int)f);                                                                     \
     ch.kern = x32 ? reinterpret_cast<const void*>(qiddm::qconv_train_backward_mfma_kernel<CO, J, float, SK, SC>)   \
-                  : reinterpret_cast<const void*>(qiddm::qconv_train_backward_mfma_kernel<CO, J, double, SK, SC>); \
+                  : (bn ? tm_bn_kernel<CO, J, SK, SC>()                                                            \
+                        : reinterpret_cast<const void*>(qiddm::qconv_train_backward_mfma_kernel<CO, J, double, SK, SC>)); \
   }
   QIDDM_TM_SCASE(8, 2, 1, 16)
   QIDDM_TM_SCASE(8, 4, 3, 16)
@@ -403,6 +414,19 @@ int64_t qiddm_qconv_train_dx_elems(int32_t n_qubits, int64_t batch, int64_t in_c
   return tc.M * (2 * (int64_t)row_channels + 1);
 }
 
+int32_t qiddm_qconv_train_bn_ok(int64_t batch, int64_t in_channels, int64_t height, int64_t width, int64_t kh, int64_t kw,
+                                int64_t pad_h, int64_t pad_w, int64_t out_channels, int32_t row_channels) {
+  if (batch < 1 || in_channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad_h < 0 || pad_w < 0 ||
+      out_channels < 1)
+    return 0;
+  const int64_t ho = height + 2 * pad_h - kh + 1, wo = width + 2 * pad_w - kw + 1;
+  if (ho < 1 || wo < 1) return 0;
+  const int64_t f = in_channels * kh * kw;
+  const bool fits = train_fits32(batch, in_channels, height, width, out_channels, ho, wo);
+  if (!train_mfma_choice(f, row_channels, fits, false, kh, kw, in_channels).kern) return 1;   // the VALU kernel folds it
+  return train_mfma_choice(f, row_channels, fits, false, kh, kw, in_channels, true).kern != nullptr ? 1 : 0;
+}
+
 int qiddm_qconv_train_backward_bn(int32_t n_qubits, const double* x, int64_t batch, int64_t in_channels, int64_t height,
                                   int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
                                   const double* grad_out, const double* conv_y, const double* bn_coef,
@@ -496,9 +520,11 @@ int train_backward(int32_t n_qubits, const void* x, bool x32, int64_t batch, int
   const void* kern = nullptr;
   unsigned threads = qiddm::kTcThreads;
   // the three products on the f32 matrix cores (qsim_qconv_train_mfma.h) where train_mfma_choice() says so
-  const TmChoice tm = train_mfma_choice(f, row_channels,
-                                        train_fits32(batch, in_channels, height, width, out_channels, ho, wo), x32, kh, kw,
-                                        in_channels);
+  TmChoice tm = train_mfma_choice(f, row_channels,
+                                  train_fits32(batch, in_channels, height, width, out_channels, ho, wo), x32, kh, kw,
+                                  in_channels, bn_y != nullptr);
+  if (bn_y && tm.smem && !tm.kern)
+    return fail(QIDDM_ERR_UNSUPPORTED, "no BatchNorm-folding variant for this layer (qiddm_qconv_train_bn_ok() == 0)");
   if (tm.kern) {
     kern = tm.kern;
     smem = tm.smem;

@@ -91,6 +91,17 @@ __global__ __launch_bounds__(kTcThreads, 1) void qconv_train_backward_kernel(con
   const int jq = (F + NW - 1) / NW;
   const int j_lo = q * jq < F ? q * jq : F, j_hi = (j_lo + jq < F) ? j_lo + jq : F;
 
+  // BatchNorm coefficients of this thread's channels (TrainConv::bn_coef), once
+  double bn_a[CQ], bn_b[CQ], bn_c[CQ];
+#pragma unroll
+  for (int i = 0; i < CQ; ++i) {
+    const int c = q * CQ + i;
+    const bool on = tc.bn_y != nullptr && c < tc.C_out;
+    bn_a[i] = on ? tc.bn_coef[c] : 1.0;
+    bn_b[i] = on ? tc.bn_coef[tc.C_out + c] : 0.0;
+    bn_c[i] = on ? tc.bn_coef[2 * tc.C_out + c] : 0.0;
+  }
+
   const int64_t pixels = (int64_t)tc.Ho * tc.Wo;
   const int64_t tiles = (tc.M + kTcTile - 1) / kTcTile;
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
@@ -158,8 +169,7 @@ __global__ __launch_bounds__(kTcThreads, 1) void qconv_train_backward_kernel(con
         if (valid && c < tc.C_out && p2 * tc.post_scale <= 1.0f) {
           double g = gpix[(size_t)c * pixels];
           if (tc.bn_y)
-            g = fma(tc.bn_coef[c], g, fma(tc.bn_coef[tc.C_out + c], tc.bn_y[(size_t)b * tc.C_out * pixels + pix + (size_t)c * pixels],
-                                          tc.bn_coef[2 * tc.C_out + c]));
+            g = fma(bn_a[i], g, fma(bn_b[i], tc.bn_y[(size_t)b * tc.C_out * pixels + pix + (size_t)c * pixels], bn_c[i]));
           t = (float)g * tc.post_scale;
         }
         dotp = fmaf(2.0f * t, p2, dotp);

@@ -41,12 +41,23 @@ __host__ __device__ inline size_t tm_lds_bytes(int F) {
           (size_t)kTmTile * (CO + 1) + (size_t)kTmWaves * kTmTile + 2 * kTmTile) * sizeof(float) +
          (size_t)F * sizeof(uint32_t);
 }
+// ... and, behind those, the three BatchNorm coefficients per channel (float64; TrainConv::bn_coef) when the layer is
+// followed by one
+template <int CO>
+__host__ __device__ inline size_t tm_coef_offset(int F) { return (tm_lds_bytes<CO>(F) + 7) / 8 * 8; }
+template <int CO>
+__host__ __device__ inline size_t tm_lds_bytes_bn(int F) { return tm_coef_offset<CO>(F) + (size_t)3 * CO * sizeof(double); }
 
 // XT: element type of x -- the float64 activations as the reference holds them, or a float32 copy (same values after
 // the (float) conversion every patch element goes through here; half the registers per load in flight)
 // SK, SC: kernel extent (SK x SK) and input channels as compile-time constants (0: run-time).  With both known the walk
 // over a wave's patch columns has no control flow at all: three instructions per load instead of ~25 and three branches
-template <int CO, int JBMAX, typename XT, int SK = 0, int SC = 0>
+// BN: the layer is followed by a training-mode BatchNorm2d whose backward transform is applied to dL/dy here
+//     (TrainConv::bn_y / bn_coef; the convolution's own output rides in registers next to dL/dy, a tile ahead).  A
+//     template parameter, not a run-time test: the extra registers cost the CO = 32 variants their second wave per SIMD
+//     (spills), so those layers keep the separate BatchNorm pass (qiddm_qconv_train_bn_ok) and every other variant is
+//     compiled without the code.
+template <int CO, int JBMAX, typename XT, int SK = 0, int SC = 0, bool BN = false>
 __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_backward_mfma_kernel(const XT* __restrict__ x,
                                                                                const double* __restrict__ gy,
                                                                                const float* __restrict__ rt,
@@ -67,6 +78,7 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
   float* s_inv = s_n2 + kTmWaves * kTmTile;           // [64]
   float* s_dot = s_inv + kTmTile;                     // [64]
   uint32_t* s_tap = reinterpret_cast<uint32_t*>(s_dot + kTmTile);  // [F]: offset | di << 24 | dj << 28
+  double* s_coef = reinterpret_cast<double*>(smem_raw + tm_coef_offset<CO>(tc.F));   // [3][CO], only with tc.bn_y
   const int tid = threadIdx.x, lane = tid & 63;
   const int q = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index, provably uniform: scalar addressing and branches
   const int l15 = lane & 15, l4 = lane >> 4, l31 = lane & 31, l5 = lane >> 5;
@@ -78,6 +90,12 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
     s_rt[i] = v;
   }
   for (int i = tid; i < kTmTile * FS; i += kTmThreads) s_v[i] = 0.f;
+  if constexpr (BN) {   // (read per tile from LDS: scalar loads from memory sat on every tile's critical path)
+    for (int i = tid; i < 3 * CO; i += kTmThreads) {
+      const int k = i / CO, c = i - k * CO;
+      s_coef[i] = c < tc.C_out ? tc.bn_coef[k * tc.C_out + c] : 0.0;
+    }
+  }
   // persistent accumulators of product (3): this wave's feature-column blocks jb = q, q + 4, ...
   f32x4 acch[JBMAX][NBC];
 #pragma unroll
@@ -110,7 +128,7 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
   constexpr int GC = CO / kTmWaves;
   static_assert(PRE <= 64, "one in-image bit per prefetched column in a 64-bit mask");
   XT raw[PRE];
-  double graw[GC], yraw[GC];   // dL/dy of the tile in flight (and, in front of a BatchNorm, the convolution's own output)
+  double graw[GC], yraw[BN ? GC : 1];   // dL/dy of the tile in flight (and, BN, the convolution's own output)
   uint64_t inb_mask = 0;
   uint32_t glive_mask = 0;
   int g_i0 = 0, g_j0 = 0;
@@ -167,10 +185,10 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
       const bool live = valid && c < tc.C_out;
       glive_mask |= (uint32_t)live << cu;
       graw[cu] = 0.0;
-      yraw[cu] = 0.0;
+      if constexpr (BN) yraw[cu] = 0.0;
       if (c < tc.C_out) {   // wave-uniform; tail pixels read pixel M - 1
         graw[cu] = gy[gpix + (uint32_t)c * (uint32_t)pixels];
-        if (tc.bn_y) yraw[cu] = tc.bn_y[gpix + (uint32_t)c * (uint32_t)pixels];
+        if constexpr (BN) yraw[cu] = tc.bn_y[gpix + (uint32_t)c * (uint32_t)pixels];
       }
     }
     inb_mask = 0;
@@ -297,9 +315,9 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
 #pragma unroll
       for (int cu = 0; cu < GC; ++cu) {
         double g = graw[cu];
-        if (tc.bn_y) {   // through the BatchNorm behind the convolution: three per-channel coefficients (scalar loads)
-          const int c = q + kTmWaves * cu < tc.C_out ? q + kTmWaves * cu : 0;
-          g = fma(tc.bn_coef[c], g, fma(tc.bn_coef[tc.C_out + c], yraw[cu], tc.bn_coef[2 * tc.C_out + c]));
+        if constexpr (BN) {   // through the BatchNorm behind the convolution: three per-channel coefficients
+          const int c = q + kTmWaves * cu;   // (< CO)
+          g = fma(s_coef[c], g, fma(s_coef[CO + c], yraw[cu], s_coef[2 * CO + c]));
         }
         s_t[lane * TS + q + kTmWaves * cu] = ((glive_mask >> cu) & 1) ? (float)g * tc.post_scale : 0.f;
       }

@@ -104,7 +104,8 @@ class QConv2d(torch.nn.Module):
                 and x.numel() > 0 and x.shape[1] == self.in_channels and _c._default_precision == "f32"
                 and _c._QCONV_BN_FUSED
                 and _c.qconv_unitary_trainable(self.wires, self.in_channels, self.kernel_size, self.out_channels)
-                and _c.batch_norm_eligible(bn, self.out_channels)):
+                and _c.batch_norm_eligible(bn, self.out_channels)
+                and _c.qconv_bn_foldable(tuple(x.shape), self.wires, self.out_channels, self.kernel_size, self.padding)):
             return None
         angles = _c.on_weight_grad_stream(lambda w: _qw_tanh(w.double()), self.weights)
         return _c.qconv_bn_train(x.double(), angles, bn, self.wires, self.out_channels, self.kernel_size, self.padding)

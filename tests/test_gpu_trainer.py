@@ -306,7 +306,11 @@ def test_qconv_batchnorm_pair_as_one_node_matches_the_two_modules(c_in, c_out, k
 
     out1, gx1, gp1, buf1, node1 = run(True)
     out0, gx0, gp0, buf0, node0 = run(False)
-    assert node1 == "_QConvBNTrainFunctionBackward" and node0 == "_BatchNormTrainFunctionBackward"
+    # (the matrix-core kernel with 32 row channels has no registers left for the fold: that layer keeps two nodes)
+    foldable = circuit.qconv_bn_foldable((4, c_in) + tuple(hw), nn.QConv2d(c_in, c_out, k, pad, 2).wires, c_out, (k, k), (pad, pad))
+    assert foldable == (c_out <= 16)
+    assert node1 == ("_QConvBNTrainFunctionBackward" if foldable else "_BatchNormTrainFunctionBackward")
+    assert node0 == "_BatchNormTrainFunctionBackward"
     assert torch.equal(out1, out0)
     for n in buf1:
         assert torch.equal(buf1[n], buf0[n]), n
