@@ -492,14 +492,17 @@ int qiddm_qconv_train_backward_x32(int32_t n_qubits, const float *x, int64_t bat
  * row_channels + 1) times less memory traffic than grad_features_t + fold.  Same-size convolutions (Ho = H, Wo = W) on the
  * matrix-core kernel with at most 32 input channels: qiddm_qconv_train_dx_elems() returns 0 for anything else, and
  * qiddm_qconv_train_backward_dx then QIDDM_ERR_UNSUPPORTED (use qiddm_qconv_train_backward).  Same h_partials; grad_x
- * agrees with the fold route to float32 rounding (the nine taps are summed in float32 instead of float64).         */
+ * agrees with the fold route to float32 rounding (the nine taps are summed in float32 instead of float64).
+ * grad_y_batch_stride: elements between two images of grad_y, 0 = dense (out_channels Ho Wo); a channel slice of a wider
+ * contiguous tensor -- one half of a concatenation's gradient -- is read in place.                                   */
 int64_t qiddm_qconv_train_dx_elems(int32_t n_qubits, int64_t batch, int64_t in_channels, int64_t height, int64_t width,
                                    int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, int64_t out_channels,
                                    int32_t row_channels);
 int qiddm_qconv_train_backward_dx(int32_t n_qubits, const double *x, int64_t batch, int64_t in_channels,
                                   int64_t height, int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
-                                  const double *grad_y, int64_t out_channels, const float *rows, int32_t row_channels,
-                                  float *pixel_rows, float *h_partials, double *grad_x, void *stream);
+                                  const double *grad_y, int64_t grad_y_batch_stride, int64_t out_channels,
+                                  const float *rows, int32_t row_channels, float *pixel_rows, float *h_partials,
+                                  double *grad_x, void *stream);
 /* The same backward for a convolution that is followed by a training-mode BatchNorm2d (every `net` of unet_simple,
  * reference nn/unet_simple.py:9-18): grad_out is dL/d(BatchNorm output), conv_y the convolution's own output and
  * bn_coef the (3, out_channels) coefficients of qiddm_batchnorm_backward_stats; the kernels form

@@ -204,8 +204,8 @@ def _declare(lib):
     lib.qiddm_qconv_train_dx_elems.restype = ctypes.c_int64
     lib.qiddm_qconv_train_dx_elems.argtypes = [ctypes.c_int32, i64, i64, i64, i64, i64, i64, i64, i64, i64, ctypes.c_int32]
     lib.qiddm_qconv_train_backward_dx.restype = ctypes.c_int
-    lib.qiddm_qconv_train_backward_dx.argtypes = [ctypes.c_int32, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, vp,
-                                                  ctypes.c_int32, vp, vp, vp, vp]
+    lib.qiddm_qconv_train_backward_dx.argtypes = [ctypes.c_int32, vp, i64, i64, i64, i64, i64, i64, i64, i64, vp, i64, i64,
+                                                  vp, ctypes.c_int32, vp, vp, vp, vp]
     lib.qiddm_matrix_adjoint_partials.restype = ctypes.c_int64
     lib.qiddm_matrix_adjoint_partials.argtypes = [i64]
     lib.qiddm_matrix_adjoint_workspace_bytes.restype = ctypes.c_int64

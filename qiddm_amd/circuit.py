@@ -927,7 +927,6 @@ def _qconv_unitary_backward(x, angles, u, cfg, grad_y, need_gx, need_ga, bn=None
     # pass; its gather then holds half the bytes in flight)
     x32 = bn is None and _QCONV_X32 and bool(lib.qiddm_qconv_train_x32_ok(b, c, h, w, kh, kw, ph, pw, c_out, co))
     xx = x.detach().to(device=device, dtype=torch.float32).contiguous() if x32 else _as_f64(x, device).contiguous()
-    gy = _as_f64(grad_y, device).contiguous()
     n_part = lib.qiddm_qconv_train_partials(b, ho, wo, f)
     hpart = torch.empty(n_part, 2 * co, f + 1, dtype=torch.float32, device=device)
     gx = torch.empty(b, c, h, w, dtype=torch.float64, device=device) if need_gx else None
@@ -937,6 +936,16 @@ def _qconv_unitary_backward(x, angles, u, cfg, grad_y, need_gx, need_ga, bn=None
         lib.qiddm_qconv_train_dx_elems(n_qubits, b, c, h, w, kh, kw, ph, pw, c_out, co)
     wpix = torch.empty(dx_elems, dtype=torch.float32, device=device) if dx_elems > 0 else None
     gfeat_t = torch.empty(f, b * ho * wo, dtype=torch.float32, device=device) if wpix is None else None
+    # a channel slice of a wider contiguous gradient (one half of torch.cat's backward) is read in place by the
+    # per-pixel-row entry point; anything else is made dense first
+    gy = _as_f64(grad_y, device)
+    gy_bstride = 0
+    if wpix is not None and bn is None and not gy.is_contiguous() and gy.dim() == 4 and b > 1 \
+            and gy.stride()[1:] == (ho * wo, wo, 1) and gy.stride(0) >= c_out * ho * wo \
+            and b * gy.stride(0) < (1 << 32):
+        gy_bstride = gy.stride(0)
+    else:
+        gy = gy.contiguous()
 
     def ptr(t):
         return 0 if t is None else t.data_ptr()
@@ -948,8 +957,8 @@ def _qconv_unitary_backward(x, angles, u, cfg, grad_y, need_gx, need_ga, bn=None
                                                       ptr(gfeat_t), ptr(wpix), hpart.data_ptr(), ptr(gx), st))
     elif wpix is not None:
         _capi.check(lib.qiddm_qconv_train_backward_dx(n_qubits, xx.data_ptr(), b, c, h, w, kh, kw, ph, pw,
-                                                      gy.data_ptr(), c_out, rt.data_ptr(), co, wpix.data_ptr(),
-                                                      hpart.data_ptr(), gx.data_ptr(), st))
+                                                      gy.data_ptr(), gy_bstride, c_out, rt.data_ptr(), co,
+                                                      wpix.data_ptr(), hpart.data_ptr(), gx.data_ptr(), st))
     else:
         entry = lib.qiddm_qconv_train_backward_x32 if x32 else lib.qiddm_qconv_train_backward
         _capi.check(entry(n_qubits, xx.data_ptr(), b, c, h, w, kh, kw, ph, pw, gy.data_ptr(), c_out, rt.data_ptr(),

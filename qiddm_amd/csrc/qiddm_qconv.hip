@@ -330,7 +330,7 @@ int train_backward(int32_t n_qubits, const void* x, bool x32, int64_t batch, int
                    int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, const double* grad_y,
                    int64_t out_channels, const float* rows, int32_t row_channels, float* grad_features_t,
                    float* pixel_rows, float* h_partials, double* grad_x, void* stream, const double* bn_y = nullptr,
-                   const double* bn_coef = nullptr);
+                   const double* bn_coef = nullptr, int64_t grad_y_batch_stride = 0);
 
 // dL/dx from per-pixel rows (qsim_qconv_dx.h) instead of feature gradients + fold: the matrix-core kernel, a same-size
 // convolution, at most 32 input channels, LDS of the dx kernel within the limit.  QIDDM_QCONV_FOLD=1 switches it off.
@@ -391,6 +391,7 @@ qiddm::TrainConv train_geometry(int32_t n_qubits, int64_t batch, int64_t in_chan
   tc.C_out = (int32_t)out_channels;
   tc.F = (int32_t)f;
   tc.M = batch * ho * wo;
+  tc.gy_bstride = out_channels * ho * wo;
   tc.pad_norm2 = 0.25f * (float)(d - f);
   tc.post_scale = 0.5f * (float)d;
   return tc;
@@ -444,14 +445,16 @@ int qiddm_qconv_train_backward_bn(int32_t n_qubits, const double* x, int64_t bat
 
 int qiddm_qconv_train_backward_dx(int32_t n_qubits, const double* x, int64_t batch, int64_t in_channels, int64_t height,
                                   int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w,
-                                  const double* grad_y, int64_t out_channels, const float* rows, int32_t row_channels,
-                                  float* pixel_rows, float* h_partials, double* grad_x, void* stream) {
+                                  const double* grad_y, int64_t grad_y_batch_stride, int64_t out_channels,
+                                  const float* rows, int32_t row_channels, float* pixel_rows, float* h_partials,
+                                  double* grad_x, void* stream) {
   if (!pixel_rows || !grad_x) return fail(QIDDM_ERR_INVALID, "pixel_rows/grad_x is NULL");
   if (qiddm_qconv_train_dx_elems(n_qubits, batch, in_channels, height, width, kh, kw, pad_h, pad_w, out_channels,
                                  row_channels) <= 0)
     return fail(QIDDM_ERR_UNSUPPORTED, "this layer keeps the feature-gradient route (qiddm_qconv_train_dx_elems() == 0)");
   return train_backward(n_qubits, x, false, batch, in_channels, height, width, kh, kw, pad_h, pad_w, grad_y,
-                        out_channels, rows, row_channels, nullptr, pixel_rows, h_partials, grad_x, stream);
+                        out_channels, rows, row_channels, nullptr, pixel_rows, h_partials, grad_x, stream, nullptr, nullptr,
+                        grad_y_batch_stride);
 }
 
 int32_t qiddm_qconv_train_x32_ok(int64_t batch, int64_t in_channels, int64_t height, int64_t width, int64_t kh,
@@ -491,7 +494,7 @@ int train_backward(int32_t n_qubits, const void* x, bool x32, int64_t batch, int
                    int64_t width, int64_t kh, int64_t kw, int64_t pad_h, int64_t pad_w, const double* grad_y,
                    int64_t out_channels, const float* rows, int32_t row_channels, float* grad_features_t,
                    float* pixel_rows, float* h_partials, double* grad_x, void* stream, const double* bn_y,
-                   const double* bn_coef) {
+                   const double* bn_coef, int64_t grad_y_batch_stride) {
   if ((bn_y == nullptr) != (bn_coef == nullptr)) return fail(QIDDM_ERR_INVALID, "bn_y and bn_coef go together");
   if (n_qubits < 1 || n_qubits > 12) return fail(QIDDM_ERR_UNSUPPORTED, "n_qubits=%d outside 1..12", n_qubits);
   if (batch < 1 || in_channels < 1 || height < 1 || width < 1 || kh < 1 || kw < 1 || pad_h < 0 || pad_w < 0 ||
@@ -513,6 +516,12 @@ int train_backward(int32_t n_qubits, const void* x, bool x32, int64_t batch, int
   tc.groups = train_groups(f);
   tc.bn_y = bn_y;
   tc.bn_coef = bn_coef;
+  if (grad_y_batch_stride != 0) {
+    if (grad_y_batch_stride < tc.gy_bstride) return fail(QIDDM_ERR_INVALID, "grad_y_batch_stride smaller than an image");
+    if (batch * grad_y_batch_stride >= ((int64_t)1 << 32))
+      return fail(QIDDM_ERR_UNSUPPORTED, "strided grad_y beyond 2^32 elements");
+    tc.gy_bstride = grad_y_batch_stride;
+  }
   tc.stamps = qiddm_capi::stamp_buffer(8);
   const unsigned grid = (unsigned)train_grid(batch * ho * wo, f);
   hipStream_t st = static_cast<hipStream_t>(stream);

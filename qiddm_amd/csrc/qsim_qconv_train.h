@@ -29,6 +29,8 @@ struct TrainConv {
   int32_t C, H, W, kh, kw, ph, pw, Ho, Wo, C_out, F;
   int32_t groups;     // thread groups of the h product: each owns all F + 1 columns and 64 / groups pixels of a tile
   int64_t M;          // batch * Ho * Wo
+  int64_t gy_bstride; // elements between two images of grad_y (C_out * Ho * Wo when dense; larger for a channel slice of a
+                      // wider tensor, e.g. one half of a concatenation's gradient: read in place, no copy)
   float pad_norm2;    // 0.25 * (D - F)
   float post_scale;   // D / 2
   unsigned long long* stamps;  // diagnostics (QIDDM_STAMP_PTR): per-phase s_memtime sums of workgroup 0, else null
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(kTcThreads, 1) void qconv_train_backward_kernel(con
       for (int w = 0; w < NW; ++w) nrm2 += s_sc[w * kTcTile + lane];
       const float inv = 1.0f / sqrtf(nrm2);
       // ---- this thread's channels: a, t, W2 = t (Re a, Im a) -> s_w; its share of dot = 2 sum t |a|^2 ------------------
-      const double* __restrict__ gpix = gy + (size_t)b * tc.C_out * pixels + pix;
+      const double* __restrict__ gpix = gy + (size_t)b * tc.gy_bstride + pix;
       const float* __restrict__ rp = s_rt + (size_t)F * K2;
       float dotp = 0.f;
 #pragma unroll

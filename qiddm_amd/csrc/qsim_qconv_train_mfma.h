@@ -177,7 +177,8 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
     const int oi = pix / tc.Wo, oj = pix - oi * tc.Wo;
     g_i0 = oi - tc.ph;
     g_j0 = oj - tc.pw;
-    const uint32_t gpix = (uint32_t)(b * tc.C_out * pixels + pix);
+    const uint32_t gpix = (uint32_t)(b * tc.gy_bstride + pix);
+    const uint32_t ypix = (uint32_t)(b * tc.C_out * pixels + pix);   // (the convolution's own output is dense)
     glive_mask = 0;
 #pragma unroll
     for (int cu = 0; cu < GC; ++cu) {
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(kTmThreads, (JBMAX >= 8 ? 1 : 2)) void qconv_train_
       if constexpr (BN) yraw[cu] = 0.0;
       if (c < tc.C_out) {   // wave-uniform; tail pixels read pixel M - 1
         graw[cu] = gy[gpix + (uint32_t)c * (uint32_t)pixels];
-        if constexpr (BN) yraw[cu] = tc.bn_y[gpix + (uint32_t)c * (uint32_t)pixels];
+        if constexpr (BN) yraw[cu] = tc.bn_y[ypix + (uint32_t)c * (uint32_t)pixels];
       }
     }
     inb_mask = 0;

@@ -394,3 +394,20 @@ def test_cz_kernels_without_encoding_forward_and_adjoint(n, L, S, meas, B, preci
     assert gi is None
     sw = max(wo.grad.abs().max().item(), 1e-3)
     assert (ga.cpu() - wo.grad).abs().max().item() < tol * sw, (ga.cpu() - wo.grad).abs().max().item() / sw
+
+
+def test_thin_product_backward_reads_a_channel_slice_of_the_gradient_in_place():
+    """dL/dy handed over as one half of a concatenation's gradient (a channel slice: batch stride larger than an image)
+    is read in place by the per-pixel-row backward -- bit for bit the gradients of the dense copy."""
+    from qiddm_amd import nn
+    torch.manual_seed(8)
+    layer = nn.QConv2d(16, 8, 1, 0, 2).cuda().train()          # unet_simple's last up-convolution
+    x = torch.rand(5, 16, 14, 14, dtype=torch.float64, device="cuda")
+    wide = torch.randn(5, 24, 14, 14, dtype=torch.float64, device="cuda")
+    for lo in (0, 16):
+        gy_view = wide[:, lo:lo + 8]
+        assert not gy_view.is_contiguous()
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ga = torch.autograd.grad(layer(xa), [xa, layer.weights], gy_view)
+        gb = torch.autograd.grad(layer(xb), [xb, layer.weights], gy_view.contiguous())
+        assert torch.equal(ga[0], gb[0]) and torch.equal(ga[1], gb[1])
