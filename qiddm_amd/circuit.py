@@ -762,6 +762,12 @@ def weight_grad_stream(device):
     side = _weight_grad_streams.get(idx)
     if side is None:
         side = _weight_grad_streams[idx] = torch.cuda.Stream(device=idx)
+        # a leaf's AccumulateGrad node that outlives an iteration (the previous loss still referenced) keeps the stream it
+        # was created under; the engine synchronises the two streams itself, which is all this design needs -- the
+        # warning about it would fire on every step
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:
+            quiet(False)
     return None if torch.cuda.current_stream(idx) == side else side
 
 

@@ -9,6 +9,7 @@
 #include <cstring>
 
 #include "qsim_qconv_dx.h"
+#include "qsim_qconv_fwd.h"
 #include "qsim_qconv_train.h"
 #include "qsim_qconv_train_mfma.h"
 #include "qsim_unitary.h"
@@ -211,6 +212,51 @@ int qiddm_qconv_unitary_forward(int32_t n_qubits, const double* u, const double*
   gc.pad_norm2 = 0.25 * (double)(d - f);
   gc.post_scale = 0.5 * (double)d;
   gc.stamps = qiddm_capi::stamp_buffer(8);
+  // same-size convolutions up to 32 output channels: the patch matrix from an LDS copy of the image (qsim_qconv_fwd.h)
+  // instead of kh kw gathered loads per input element.  QIDDM_QCONV_GATHER=1 keeps the gathering kernel (A/B).
+  static const bool env_gather = std::getenv("QIDDM_QCONV_GATHER") != nullptr;
+  // (1 x 1 layers have no patch reuse to exploit: the gathering kernel streams them faster -- 93 vs 110 us at 16 -> 8 channels,
+  //  2560 x 28 x 28 pixels)
+  if (!env_gather && !upsample2x && kh * kw > 1 && g.ho == h_eff && g.wo == w_eff && g.packed != 3 && g.n_pad <= 64 &&
+      in_channels < 0xffff && kh * kw <= 31 && qiddm::fwd_xs(gc) < 0xffff &&
+      batch * in_channels * h_eff * w_eff < ((int64_t)1 << 31) && g.m * out_channels < ((int64_t)1 << 31)) {
+    const void* kern = nullptr;
+    size_t smem = 0;
+    const int64_t need = ((int64_t)gc.C * qiddm::fwd_xs(gc) + qiddm::kFwdThreads - 1) / qiddm::kFwdThreads;
+#define QIDDM_FWD_PICK(NCOL)                                                                                       \
+  do {                                                                                                            \
+    smem = qiddm::fwd_lds_bytes<NCOL>(gc);                                                                         \
+    kern = need <= 1 ? reinterpret_cast<const void*>(qiddm::qconv_fwd_halo_kernel<NCOL, 1>)                         \
+           : need <= 4 ? reinterpret_cast<const void*>(qiddm::qconv_fwd_halo_kernel<NCOL, 4>)                      \
+           : need <= 12 ? reinterpret_cast<const void*>(qiddm::qconv_fwd_halo_kernel<NCOL, 12>)                    \
+                        : reinterpret_cast<const void*>(qiddm::qconv_fwd_halo_kernel<NCOL, 20>);                   \
+  } while (0)
+    if (g.n_pad == 16)
+      QIDDM_FWD_PICK(16);
+    else if (g.n_pad == 32)
+      QIDDM_FWD_PICK(32);
+    else
+      QIDDM_FWD_PICK(64);
+#undef QIDDM_FWD_PICK
+    if (need <= 40 && smem <= kMaxLds) {
+      if (smem > 48 * 1024) {
+        const hipError_t ea = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxLds);
+        if (ea != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "hipFuncSetAttribute(LDS) failed: %s", hipGetErrorString(ea));
+      }
+      const int64_t tiles = (g.m + qiddm::kFwdTile - 1) / qiddm::kFwdTile;
+      // resident workgroups only (each stages the packed operand once): by LDS and by the registers of the variant
+      const int64_t by_regs = need <= 1 ? 6 : need <= 4 ? 5 : need <= 12 ? 3 : 2;
+      const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(by_regs, (int64_t)(kMaxLds / (smem + 1024))));
+      const unsigned grid = (unsigned)std::min<int64_t>(tiles, 256 * per_cu);
+      const float* wc = w;
+      const float* pc = padv;
+      const double* bc = bnv;
+      void* args[] = {(void*)&x, (void*)&wc, (void*)&pc, (void*)&bc, (void*)&y, (void*)&gc};
+      e = hipLaunchKernel(kern, dim3(grid), dim3(qiddm::kFwdThreads), args, smem, st);
+      if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_fwd_halo_kernel launch failed: %s", hipGetErrorString(e));
+      return QIDDM_OK;
+    }
+  }
   const int64_t mblocks = (g.m + qiddm::kGemmM - 1) / qiddm::kGemmM;
   if (mblocks > 0x7fffffff) return fail(QIDDM_ERR_UNSUPPORTED, "too many output pixels for one launch");
 #define QIDDM_GEMM_LAUNCH(GRID_Y, ...)                                                                             \
