@@ -388,6 +388,8 @@ DxChoice train_dx_choice(const qiddm::TrainConv& tc, int32_t row_channels, bool 
   static const bool env_fold = std::getenv("QIDDM_QCONV_FOLD") != nullptr;
   DxChoice ch;
   if (env_fold || !mfma || tc.Ho != tc.H || tc.Wo != tc.W || tc.C > 32 || tc.kh * tc.kw > 32) return ch;
+  // (32-bit offsets inside the kernel)
+  if (tc.M * tc.C >= ((int64_t)1 << 31) || tc.M * (2 * (int64_t)row_channels + 1) >= ((int64_t)1 << 31)) return ch;
   size_t smem = 0;
   const void* kern = nullptr;
   const bool one = tc.C <= 16;   // one block of 16 input channels, or two

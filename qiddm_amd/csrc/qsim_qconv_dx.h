@@ -73,6 +73,8 @@ __global__ __launch_bounds__(kDxThreads) void qconv_dx_kernel(const double* __re
   const int64_t hw = (int64_t)tc.H * tc.W;
   const int64_t total = tc.M;                                // input pixels = output pixels (same-size convolution)
   const float* __restrict__ kvec = wpix + (size_t)total * K2;
+  // (the host sends tensors below 2^31 elements: 32-bit offsets and divisions in the tile loop)
+  const uint32_t hw32 = (uint32_t)hw, total32 = (uint32_t)total;
   const dx_f32x4* __restrict__ wpix4 = reinterpret_cast<const dx_f32x4*>(wpix);
 
   // B[(tap, cc)][c] = rt[c KK + tap][cc] (read in rt's own order: coalesced); columns c >= C are zero
@@ -89,37 +91,37 @@ __global__ __launch_bounds__(kDxThreads) void qconv_dx_kernel(const double* __re
   dx_f32x4 pre[PF];
   float pre_k = 0.f;
   auto issue_rows = [&](int64_t tile) {
-    const int64_t first = tile * kDxTile - halo;
+    const int32_t first = (int32_t)(tile * kDxTile) - halo;
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int i = tid + u * kDxThreads;
-      const int64_t m = first + i / K4;
+      const int32_t m = first + i / K4;          // (K4 is a power of two)
       pre[u] = dx_f32x4{0.f, 0.f, 0.f, 0.f};
-      if (i < n4 && m >= 0 && m < total) pre[u] = wpix4[(size_t)m * K4 + (i % K4)];
+      if (i < n4 && m >= 0 && (uint32_t)m < total32) pre[u] = wpix4[(uint32_t)m * (uint32_t)K4 + (uint32_t)(i % K4)];
     }
-    const int64_t mk = first + tid;
-    pre_k = (tid < n_src && mk >= 0 && mk < total) ? kvec[mk] : 0.f;
+    const int32_t mk = first + tid;
+    pre_k = (tid < n_src && mk >= 0 && (uint32_t)mk < total32) ? kvec[(uint32_t)mk] : 0.f;
   };
   if ((int64_t)blockIdx.x < tiles) issue_rows(blockIdx.x);
 
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
     const int64_t p0 = tile * kDxTile;
     // (image of the tile's first pixel: one 64-bit division per tile, uniform; 32-bit ones per thread from there)
-    const int64_t b0 = p0 / hw;
-    const uint32_t rem0 = (uint32_t)(p0 - b0 * hw);
+    const uint32_t b0 = (uint32_t)p0 / hw32;
+    const uint32_t rem0 = (uint32_t)p0 - b0 * hw32;
     // ---- this tile's x values: thread = (channel, pixel), pixels fastest (512-byte rows of x and gx) ------------------
     constexpr int XS = 4 * CB;   // (channel, pixel) slots of a thread: 16 CB channels x 64 pixels / 256 threads
     double xv[XS];
-    int64_t xe[XS];
+    uint32_t xe[XS];   // element offset, 0xffffffff: none
 #pragma unroll
     for (int u = 0; u < XS; ++u) {
       const int i = tid + u * kDxThreads;
       const int c = i >> 6, pl = i & 63;
-      xe[u] = -1;
+      xe[u] = 0xffffffffu;
       xv[u] = 0.0;
       if (c < C && p0 + pl < total) {
-        const uint32_t rem = rem0 + (uint32_t)pl, db = rem / (uint32_t)hw;
-        xe[u] = ((b0 + db) * C + c) * hw + (rem - db * (uint32_t)hw);
+        const uint32_t rem = rem0 + (uint32_t)pl, db = rem / hw32;
+        xe[u] = ((b0 + db) * (uint32_t)C + (uint32_t)c) * hw32 + (rem - db * hw32);
         xv[u] = x[xe[u]];
       }
     }
@@ -160,14 +162,16 @@ __global__ __launch_bounds__(kDxThreads) void qconv_dx_kernel(const double* __re
       const int64_t p = p0 + tid;
       uint32_t mask = 0;
       if (p < total) {
-        const int pix = (int)((rem0 + (uint32_t)tid) % (uint32_t)hw);
-        const int i = pix / tc.W, j = pix - i * tc.W;
+        const uint32_t pix = (rem0 + (uint32_t)tid) % hw32;
+        const int i = (int)(pix / (uint32_t)tc.W), j = (int)pix - i * tc.W;
+        uint32_t cols = 0;   // taps of one kernel row whose source column exists
+        for (int dj = 0; dj < tc.kw; ++dj) {
+          const int oj = j - dj + tc.pw;
+          cols |= (uint32_t)(oj >= 0 && oj < tc.W) << dj;
+        }
         for (int di = 0; di < tc.kh; ++di) {
           const int oi = i - di + tc.ph;
-          for (int dj = 0; dj < tc.kw; ++dj) {
-            const int oj = j - dj + tc.pw;
-            if (oi >= 0 && oi < tc.H && oj >= 0 && oj < tc.W) mask |= 1u << (di * tc.kw + dj);
-          }
+          mask |= (oi >= 0 && oi < tc.H) ? cols << (di * tc.kw) : 0u;
         }
       }
       s_mask[tid] = mask;
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(kDxThreads) void qconv_dx_kernel(const double* __re
     for (int u = 0; u < XS; ++u) {
       const int i = tid + u * kDxThreads;
       const int c = i >> 6, pl = i & 63;
-      if (xe[u] >= 0) {
+      if (xe[u] != 0xffffffffu) {
         const float v = (float)xv[u] + 0.1f;
         gx[xe[u]] = (double)(s_out[(size_t)c * (kDxTile + 1) + pl] - v * s_ks[pl]);
       }
