@@ -101,7 +101,7 @@ VALU_PEAK_TF = 157.3           # f32 vector peak (= the f32 MFMA peak), same gui
 N_QUBITS, QDEPTH, IMG = 8, 14, 28
 MIN_TIMED_S = 0.05
 HEADLINE_KERNEL = "qiddm::dense_lean_kernel<{}, 8, 4, false, 14, false>"
-TRAFFIC_PROFILE = "profiles/r03b/bench_pmc_traffic.json"     # FETCH_SIZE / WRITE_SIZE passes of the driver's command
+TRAFFIC_PROFILE = "profiles/r03c/bench_pmc_traffic.json"     # FETCH_SIZE / WRITE_SIZE passes of the driver's command
 HEADLINE_NOTE = ("latency-bound at batch 256: one sample per CU, one wavefront per SIMD, and a layer is ONE dependent chain "
                  "(every gate acts on the same 256 amplitudes): ~11 cycles per dependent vector instruction for a lone "
                  "wavefront + ~230 for the LDS exchange of the two wave-bit gates (tools/ubench/). All 14 layers of every "
