@@ -512,9 +512,24 @@ def secondary_c3_circuits(dev, out):
         tag = "C3_QDenseUndirected_old_noise(60,28)_b1024"
         out[f"denoise_images_per_s_{tag}"] = batch / (us * 1e-6)
         out[f"gate_apps_per_s_{tag}"] = batch * 1201 / (us * 1e-6)
+        # the circuit does not depend on the data: amplitude embedding -> ONE float32 product with the cached circuit unitary
+        # (1024 x 2*784 operand) -> probabilities + post-processing (qiddm_amp_embed_rows / library GEMM / qiddm_prob_post)
+        tf = 2.0 * 1024 * 2 * 784 * batch / (us * 1e-6) / 1e12
+        out[f"roofline_{tag}"] = {"bound": "mfma", "achieved": tf, "peak": VALU_PEAK_TF, "unit": "TFLOP/s",
+                                  "frac": tf / VALU_PEAK_TF, "kernel": "library sgemm (hipBLASLt) between "
+                                  "qiddm::amp_embed_rows_kernel and qiddm::prob_post_kernel", "kernel_avg_us": us,
+                                  "note": "f32 matrix-core peak = the f32 vector peak (157.3 TFLOP/s); time of all three launches"}
+        from qiddm_amd.nn import qdense as _qd
+        _qd._DENSE_UNITARY = False                # the per-sample simulation kernel on the same input, for reference
+        try:
+            with torch.no_grad():
+                us_sim = _graph_event_us(lambda: net(x), launches=10)
+        finally:
+            _qd._DENSE_UNITARY = True
+        out[f"denoise_images_per_s_{tag}_simulated"] = batch / (us_sim * 1e-6)
         flop = 60 * 10 * 1024 * 14                # general gate path: a complex 2x2 row per amplitude and Rot (14 flop)
-        out[f"roofline_{tag}"] = _valu_block(flop * batch, us, "qiddm::circuit_kernel<float, 10, false>",
-                                             "amplitude embedding + 60 x (10 Rot + CNOT ring) + probs + post-processing")
+        out[f"roofline_{tag}_simulated"] = _valu_block(flop * batch, us_sim, "qiddm::circuit_kernel<float, 10, false>",
+                                                       "amplitude embedding + 60 x (10 Rot + CNOT ring) + probs + post-processing")
     except Exception as e:  # pragma: no cover
         out["error_C3_QDenseUndirected_old_noise"] = repr(e)
 

@@ -433,6 +433,17 @@ int qiddm_upsample2x_forward(const double *x, int64_t planes, int64_t height, in
 int qiddm_upsample2x_backward(const double *grad_y, int64_t planes, int64_t height, int64_t width,
                               const double *ah, const double *aw, double *grad_x, void *stream);
 
+/* ---- the dense unitary route (A4 nets at inference) ----------------------------------------------------------------------
+ * AmplitudeEmbedding -> weight-only layers -> probs (reference nn/qdense.py:40-47) does not depend on the data beyond the
+ * embedded vector: with U = qiddm_circuit_unitary(weights), a batch is ONE real product  [Re a | Im a] = v^ [Re U^T | Im U^T]
+ * (a plain library GEMM on the caller's side) between two elementwise kernels:
+ *   qiddm_amp_embed_rows:  v (batch, 2^n) float32 = (x + offset | pad_with) / norm       (normalize=True)
+ *   qiddm_prob_post:       out (batch, cols) float64 = clamp((Re^2 + Im^2) * scale, 0, 1) from (batch, 2 cols) float32
+ * -- the move the reference itself makes for its eval-mode QConv2d (nn/qconv.py:96-113).                               */
+int qiddm_amp_embed_rows(const double *x, int64_t batch, int64_t x_ld, int64_t features, int32_t n_qubits, double pad_with,
+                         double offset, float *v, void *stream);
+int qiddm_prob_post(const float *amplitudes, int64_t batch, int64_t cols, double scale, double *out, void *stream);
+
 /* MaxPool2d(kernel_size=2, stride=2) of the UNets' down blocks (reference nn/unet.py:93-95), float64 (planes, H, W) ->
  * (planes, H/2, W/2), floor mode.  The backward recomputes the winner of every window from x (first maximum in row-major
  * order, as torch picks it) instead of keeping an index tensor and writes every element of grad_x once.         */

@@ -62,6 +62,8 @@ EXPORTS = (
     "qiddm_circuit_unitary_wide",
     "qiddm_qconv_unitary_workspace_bytes",
     "qiddm_qconv_unitary_forward",
+    "qiddm_amp_embed_rows",
+    "qiddm_prob_post",
     "qiddm_maxpool2_forward",
     "qiddm_maxpool2_backward",
     "qiddm_conv1x1_forward",
@@ -245,6 +247,10 @@ def _declare(lib):
     lib.qiddm_mixed_forward.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(MixedOp), ctypes.c_int32, vp, i64,
                                         ctypes.c_int32, vp, i64, ctypes.c_int32, ctypes.c_double, ctypes.c_double, vp,
                                         ctypes.c_int32, ctypes.c_int32, i64, vp, i64, vp, i64, vp]
+    lib.qiddm_amp_embed_rows.restype = ctypes.c_int
+    lib.qiddm_amp_embed_rows.argtypes = [vp, i64, i64, i64, ctypes.c_int32, ctypes.c_double, ctypes.c_double, vp, vp]
+    lib.qiddm_prob_post.restype = ctypes.c_int
+    lib.qiddm_prob_post.argtypes = [vp, i64, i64, ctypes.c_double, vp, vp]
     lib.qiddm_maxpool2_forward.restype = ctypes.c_int
     lib.qiddm_maxpool2_forward.argtypes = [vp, i64, i64, i64, vp, vp]
     lib.qiddm_maxpool2_backward.restype = ctypes.c_int

@@ -419,6 +419,35 @@ def circuit_unitary(angles: torch.Tensor, n_qubits: int, imprimitive: str = "CNO
     return torch.view_as_complex(u)
 
 
+def dense_unitary_operand(unitary: torch.Tensor, cols: int) -> torch.Tensor:
+    """(2^n, 2 cols) float32 operand ``[Re U^T | Im U^T]`` restricted to the first ``cols`` outcomes -- built once per
+    weights for ``dense_unitary_forward``."""
+    rows = unitary[:cols]                                   # rows k < cols of <k|U|j>
+    return torch.cat([rows.real.t(), rows.imag.t()], dim=1).to(torch.float32).contiguous()
+
+
+def dense_unitary_forward(x: torch.Tensor, operand: torch.Tensor, n_qubits: int, cols: int, pad_with: float,
+                          post_scale: float) -> torch.Tensor:
+    """``clamp(probs[:, :cols] * post_scale, 0, 1)`` of ``AmplitudeEmbedding(x, normalize=True, pad_with) -> U`` for a
+    whole batch as one float32 matrix product with the cached unitary (``qiddm_amp_embed_rows`` -> library GEMM ->
+    ``qiddm_prob_post``).  x: (B, features) float64 on the device; returns (B, cols) float64.  No autograd."""
+    _require_device(x, "the input batch")
+    device = x.device
+    xx = _as_f64(x, device)
+    if xx.stride(1) != 1:
+        xx = xx.contiguous()
+    b, f = xx.shape
+    d = 1 << n_qubits
+    lib = _capi.lib()
+    st = _stream_ptr(device)
+    v = torch.empty(b, d, dtype=torch.float32, device=device)
+    _capi.check(lib.qiddm_amp_embed_rows(xx.data_ptr(), b, xx.stride(0), f, n_qubits, float(pad_with), 0.0, v.data_ptr(), st))
+    amps = torch.mm(v, operand)                              # (B, 2 cols): the plain library GEMM
+    out = torch.empty(b, cols, dtype=torch.float64, device=device)
+    _capi.check(lib.qiddm_prob_post(amps.data_ptr(), b, cols, float(post_scale), out.data_ptr(), st))
+    return out
+
+
 _qconv_workspaces = {}
 
 

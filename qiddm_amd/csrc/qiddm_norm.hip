@@ -451,6 +451,44 @@ __global__ __launch_bounds__(256) void maxpool2_backward_kernel(const double* __
   }
 }
 
+// ---- the two elementwise ends of the dense UNITARY route (A4 nets at inference: AmplitudeEmbedding -> weight-only layers
+// -> probs, reference nn/qdense.py:40-47, 56-57; the circuit does not depend on the data, so a batch is one product with
+// the cached circuit unitary -- the same move as the reference's own eval-mode QConv2d, nn/qconv.py:96-113) -----------------
+// rows of AmplitudeEmbedding(normalize=True, pad_with): (B, F) float64 -> (B, D) float32, v / |v| with D - F pad entries
+__global__ __launch_bounds__(256) void amp_embed_rows_kernel(const double* __restrict__ x, int64_t x_ld, int64_t batch,
+                                                             int F, int D, double pad_with, double offset,
+                                                             float* __restrict__ v) {
+  __shared__ double s_red[4];
+  const int64_t b = blockIdx.x;
+  if (b >= batch) return;
+  const double* __restrict__ row = x + b * x_ld;
+  double n2 = 0.0;
+  for (int j = threadIdx.x; j < F; j += 256) {
+    const double t = row[j] + offset;
+    n2 = fma(t, t, n2);
+  }
+  for (int off = 32; off > 0; off >>= 1) n2 += __shfl_down(n2, off, 64);
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = n2;
+  __syncthreads();
+  const double tot = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]) + pad_with * pad_with * (double)(D - F);
+  const double inv = 1.0 / sqrt(tot);
+  float* __restrict__ out = v + b * (int64_t)D;
+  for (int j = threadIdx.x; j < D; j += 256) out[j] = (float)((j < F ? row[j] + offset : pad_with) * inv);
+}
+
+// probabilities of the first `cols` outcomes from (B, 2 cols) float32 amplitudes [Re | Im], post-processed:
+// out (B, cols) float64 = clamp((Re^2 + Im^2) * scale, 0, 1)
+__global__ __launch_bounds__(256) void prob_post_kernel(const float* __restrict__ a, int64_t total, int cols, double scale,
+                                                        double* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t b = i / cols;
+  const int c = (int)(i - b * cols);
+  const float re = a[b * 2 * cols + c], im = a[b * 2 * cols + cols + c];
+  const double p = (double)(re * re + im * im) * scale;
+  out[i] = p < 0.0 ? 0.0 : (p > 1.0 ? 1.0 : p);
+}
+
 }  // namespace qiddm
 
 namespace {
@@ -606,6 +644,29 @@ int qiddm_maxpool2_backward(const double* x, const double* grad_y, int64_t plane
   hipLaunchKernelGGL(qiddm::maxpool2_backward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), x, grad_y, planes, (int)height, (int)width, grad_x);
   return launched("maxpool2_backward_kernel");
+}
+
+int qiddm_amp_embed_rows(const double* x, int64_t batch, int64_t x_ld, int64_t features, int32_t n_qubits, double pad_with,
+                         double offset, float* v, void* stream) {
+  if (batch < 0 || features < 1 || n_qubits < 1 || n_qubits > 14 || features > ((int64_t)1 << n_qubits) || x_ld < features)
+    return fail(QIDDM_ERR_INVALID, "bad amplitude-embedding geometry");
+  if (batch == 0) return QIDDM_OK;
+  if (!x || !v) return fail(QIDDM_ERR_INVALID, "x/v is NULL");
+  if (batch > 0x7fffffff) return fail(QIDDM_ERR_UNSUPPORTED, "too many rows for one launch");
+  hipLaunchKernelGGL(qiddm::amp_embed_rows_kernel, dim3((unsigned)batch), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                     x_ld, batch, (int)features, 1 << n_qubits, pad_with, offset, v);
+  return launched("amp_embed_rows_kernel");
+}
+
+int qiddm_prob_post(const float* amplitudes, int64_t batch, int64_t cols, double scale, double* out, void* stream) {
+  if (batch < 0 || cols < 1 || cols > (1 << 20)) return fail(QIDDM_ERR_INVALID, "bad geometry");
+  if (batch == 0) return QIDDM_OK;
+  if (!amplitudes || !out) return fail(QIDDM_ERR_INVALID, "amplitudes/out is NULL");
+  const int64_t total = batch * cols;
+  if (total >= ((int64_t)1 << 39)) return fail(QIDDM_ERR_UNSUPPORTED, "tensor too large for one launch");
+  hipLaunchKernelGGL(qiddm::prob_post_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), amplitudes, total, (int)cols, scale, out);
+  return launched("prob_post_kernel");
 }
 
 }  // extern "C"

@@ -502,3 +502,38 @@ def test_hip_maxpool2_matches_torch(shape):
     # other pooling geometries stay with torch
     other = torch.nn.MaxPool2d(kernel_size=3, stride=2)
     assert torch.equal(max_pool2(other, x), other(x)) if shape[2] >= 3 and shape[3] >= 3 else True
+
+
+@pytest.mark.parametrize("cls_name,qdepth,side", [("QDenseUndirected_old", 3, 8), ("QDenseUndirected_old_noise", 5, 28),
+                                                  ("QDenseUndirected_old_noise", 2, 5)])
+def test_dense_unitary_route_matches_simulation_and_oracle(cls_name, qdepth, side, monkeypatch):
+    """A4 nets at inference from 256 samples on: one float32 product with the cached circuit unitary
+    (qiddm_amp_embed_rows -> GEMM -> qiddm_prob_post) against the per-sample simulation kernel and the oracle; the cache
+    follows in-place weight updates; smaller batches keep the simulation."""
+    from qiddm_amd import nn
+    from qiddm_amd.nn import qdense
+    torch.manual_seed(13)
+    net = getattr(nn, cls_name)(qdepth, side).to(DEV).eval()
+    x = torch.rand(300, 1, side, side, dtype=torch.float64, device=DEV)
+    calls = {"unitary": 0}
+    real = qdense._c.dense_unitary_forward
+
+    def spy(*a, **k):
+        calls["unitary"] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(qdense._c, "dense_unitary_forward", spy)
+    with torch.no_grad():
+        for _ in range(2):
+            got = net(x)
+            assert calls["unitary"] >= 1
+            monkeypatch.setattr(qdense, "_DENSE_UNITARY", False)
+            sim = net(x)
+            monkeypatch.setattr(qdense, "_DENSE_UNITARY", True)
+            assert torch.allclose(got, sim, atol=2e-4), (got - sim).abs().max()
+            wm = "qw_tanh" if cls_name == "QDenseUndirected_old" else "tanh"
+            ref = oc.qdense_undirected_forward(x[:16].cpu(), net.weights.detach().cpu(), (side, side), wm)
+            assert torch.allclose(got[:16].cpu(), ref, atol=2e-4), (got[:16].cpu() - ref).abs().max()
+            net.weights.mul_(1.2)                     # the operand is rebuilt for the new weights
+        before = calls["unitary"]
+        net(x[:qdense._UNITARY_ROUTE_MIN_BATCH - 1])
+        assert calls["unitary"] == before             # below the batch threshold: the simulation kernel
