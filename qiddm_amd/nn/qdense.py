@@ -203,6 +203,8 @@ class QDenseUndirected_old(_QuantumNet):
         stamp = (w._version, w.data_ptr(), str(w.device))
         cached = getattr(self, "_unitary_operand_cache", None)
         if cached is None or cached[0] != stamp:
+            if torch.cuda.is_current_stream_capturing():
+                return None                   # (a recording computes nothing: warm the cache with one eager call first)
             u = _c.circuit_unitary(self._weight_map(w.detach().double()), self.wires, "CNOT", precision="f64")
             cached = (stamp, _c.dense_unitary_operand(u, self.pixels))
             self._unitary_operand_cache = cached
@@ -217,11 +219,12 @@ class QDenseUndirected_old(_QuantumNet):
             # inference: embedding, circuit and post-processing in one launch (no (B, 2^n) probability matrix)
             circ = _c.Circuit(n_qubits=self.wires, encoding="amplitude", imprimitive="CNOT", measure="probs",
                               n_rounds=1, n_blocks=1, sel_layers=self.qdepth, n_features=self.pixels, pad_with=0.1)
-            if b >= _UNITARY_ROUTE_MIN_BATCH and _c._default_precision == "f32" and _DENSE_UNITARY:
+            operand = self._unitary_operand() if (b >= _UNITARY_ROUTE_MIN_BATCH and _c._default_precision == "f32"
+                                                  and _DENSE_UNITARY) else None
+            if operand is not None:
                 # the circuit does not depend on the data: one float32 product with the circuit unitary (cached per
                 # weights) instead of simulating every sample (C3's batch of 1024: 193 -> 45 us)
-                out = _c.dense_unitary_forward(flat, self._unitary_operand(), self.wires, self.pixels, 0.1,
-                                               float(self.pixels))
+                out = _c.dense_unitary_forward(flat, operand, self.wires, self.pixels, 0.1, float(self.pixels))
                 return out.reshape(b, 1, self.width, self.height)
             angles, table = self._gate_table(circ, self.weights, self._weight_map)
             out = _c.run_forward_post(circ, flat, angles, self.pixels, float(self.pixels), table=table)
