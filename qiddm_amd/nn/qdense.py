@@ -196,14 +196,15 @@ class QDenseUndirected_old(_QuantumNet):
     def _post_process(self, probs):
         return torch.clamp(probs[:, : self.pixels] * self.pixels, 0, 1)
 
-    def _unitary_operand(self):
+    def _unitary_operand(self, build=True):
         """``[Re U^T | Im U^T]`` of the weight-only layers for the first ``pixels`` outcomes, float32, rebuilt when the
-        weights changed (``circuit.dense_unitary_forward``)."""
+        weights changed (``circuit.dense_unitary_forward``).  ``build=False``: only what is cached for the current
+        weights, else None."""
         w = self.weights
         stamp = (w._version, w.data_ptr(), str(w.device))
         cached = getattr(self, "_unitary_operand_cache", None)
         if cached is None or cached[0] != stamp:
-            if torch.cuda.is_current_stream_capturing():
+            if not build or torch.cuda.is_current_stream_capturing():
                 return None                   # (a recording computes nothing: warm the cache with one eager call first)
             u = _c.circuit_unitary(self._weight_map(w.detach().double()), self.wires, "CNOT", precision="f64")
             cached = (stamp, _c.dense_unitary_operand(u, self.pixels))
@@ -219,8 +220,10 @@ class QDenseUndirected_old(_QuantumNet):
             # inference: embedding, circuit and post-processing in one launch (no (B, 2^n) probability matrix)
             circ = _c.Circuit(n_qubits=self.wires, encoding="amplitude", imprimitive="CNOT", measure="probs",
                               n_rounds=1, n_blocks=1, sel_layers=self.qdepth, n_features=self.pixels, pad_with=0.1)
-            operand = self._unitary_operand() if (b >= _UNITARY_ROUTE_MIN_BATCH and _c._default_precision == "f32"
-                                                  and _DENSE_UNITARY) else None
+            # (building the unitary costs one 2^n-sample simulation: worth it from _UNITARY_ROUTE_MIN_BATCH samples on;
+            #  once it is there for the current weights every batch size takes it)
+            operand = self._unitary_operand(build=b >= _UNITARY_ROUTE_MIN_BATCH) \
+                if (_c._default_precision == "f32" and _DENSE_UNITARY) else None
             if operand is not None:
                 # the circuit does not depend on the data: one float32 product with the circuit unitary (cached per
                 # weights) instead of simulating every sample (C3's batch of 1024: 193 -> 45 us)

@@ -535,5 +535,9 @@ def test_dense_unitary_route_matches_simulation_and_oracle(cls_name, qdepth, sid
             assert torch.allclose(got[:16].cpu(), ref, atol=2e-4), (got[:16].cpu() - ref).abs().max()
             net.weights.mul_(1.2)                     # the operand is rebuilt for the new weights
         before = calls["unitary"]
-        net(x[:qdense._UNITARY_ROUTE_MIN_BATCH - 1])
-        assert calls["unitary"] == before             # below the batch threshold: the simulation kernel
+        small = x[:qdense._UNITARY_ROUTE_MIN_BATCH - 1]
+        net(small)
+        assert calls["unitary"] == before             # stale cache, below the batch threshold: the simulation kernel
+        net(x)
+        net(small)
+        assert calls["unitary"] == before + 2         # once the unitary of these weights exists every batch takes it
