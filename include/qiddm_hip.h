@@ -389,6 +389,9 @@ int qiddm_circuit_unitary(const qiddm_circuit_t *circ, const double *angles, dou
 /* n <= 12 (C4's 12-qubit layers): writes the TRANSPOSE, ut[j][k] = <k|U|j> (each column of U contiguous: the
  * workgroup of column j evolves |j> in place in row j, no workspace).  Pass u_transposed = 1 below.          */
 int qiddm_circuit_unitary_wide(const qiddm_circuit_t *circ, const double *angles, double *ut, void *stream);
+/* The forward first packs the rows of u it needs (and the folded BatchNorm) into `workspace`.  u == NULL skips that launch:
+ * `workspace` must then still hold the packing of an earlier call for the same unitary, batch norm and geometry -- an
+ * eval-mode layer whose weights have not changed keeps its own workspace and packs once.                          */
 int64_t qiddm_qconv_unitary_workspace_bytes(int32_t n_qubits, int64_t in_channels, int64_t kh, int64_t kw,
                                             int64_t out_channels);
 int qiddm_qconv_unitary_forward(int32_t n_qubits, const double *u, const double *x, int64_t batch,

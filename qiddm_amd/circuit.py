@@ -452,15 +452,18 @@ _qconv_workspaces = {}
 
 
 def qconv_unitary_forward(x: torch.Tensor, unitary: torch.Tensor, n_qubits: int, out_channels: int, kernel_size,
-                          padding, upsample2x: bool = False, batch_norm: torch.nn.BatchNorm2d | None = None
-                          ) -> torch.Tensor:
+                          padding, upsample2x: bool = False, batch_norm: torch.nn.BatchNorm2d | None = None,
+                          packed: dict | None = None, packed_key=None) -> torch.Tensor:
     """The eval-mode QConv2d forward (reference nn/qconv.py:105-113 + :58-69): unfold -> +0.1 ->
     AmplitudeEmbedding(pad 0.5) -> QubitUnitary(unitary) -> probs -> post-processing, as one implicit-im2col GEMM
     on the f32 matrix cores (``qiddm_qconv_unitary_forward``).  x (B, C, H, W) -> (B, out_channels, Ho, Wo)
     float64; ``unitary`` (D, D) complex128 from ``circuit_unitary``.
 
     ``upsample2x``: convolve ``Upsample(scale_factor=2, mode="bilinear")(x)`` without materialising it;
-    ``batch_norm``: apply this (eval-mode, running statistics) BatchNorm2d to the output in the epilogue."""
+    ``batch_norm``: apply this (eval-mode, running statistics) BatchNorm2d to the output in the epilogue.
+    ``packed`` / ``packed_key``: a dict owned by the caller (an eval-mode layer) and a key that changes with the
+    unitary: the packed GEMM operand is kept there, with the BatchNorm's tensor versions, and the pack launch is
+    skipped while nothing changed."""
     _require_device(unitary, "the circuit unitary")
     _require_device(x, "the input batch")
     device = unitary.device
@@ -477,7 +480,20 @@ def qconv_unitary_forward(x: torch.Tensor, unitary: torch.Tensor, n_qubits: int,
     need = lib.qiddm_qconv_unitary_workspace_bytes(n_qubits, c, kh, kw, out_channels)
     if need < 0:
         _capi.check(int(need))
-    ws = _scratch(_qconv_workspaces, "qconv", need, device)
+    reuse = False
+    if packed is not None and packed_key is not None and not torch.cuda.is_current_stream_capturing():
+        bn_key = None if batch_norm is None else tuple(
+            (None if t is None else (t._version, t.data_ptr()))
+            for t in (batch_norm.weight, batch_norm.bias, batch_norm.running_mean, batch_norm.running_var)) + (batch_norm.eps,)
+        key = (packed_key, bn_key, n_qubits, c, kh, kw, out_channels, str(device))
+        entry = packed.get("entry")
+        if entry is not None and entry[0] == key:
+            ws, reuse = entry[1], True
+        else:
+            ws = torch.empty(max(int(need), 1), dtype=torch.uint8, device=device)
+            packed["entry"] = (key, ws)
+    else:
+        ws = _scratch(_qconv_workspaces, "qconv", need, device)
     he, we = (2 * h, 2 * w) if upsample2x else (h, w)
     ho, wo = he + 2 * ph - kh + 1, we + 2 * pw - kw + 1
     y = torch.empty(b, out_channels, max(ho, 0), max(wo, 0), dtype=torch.float64, device=device)
@@ -497,7 +513,7 @@ def qconv_unitary_forward(x: torch.Tensor, unitary: torch.Tensor, n_qubits: int,
                                           running_mean=f64(batch_norm.running_mean),
                                           running_var=f64(batch_norm.running_var), eps=float(batch_norm.eps))
         bn_ref = ctypes.byref(bn_struct)
-    _capi.check(lib.qiddm_qconv_unitary_forward(n_qubits, ur.data_ptr(), xx.data_ptr(), b, c, h, w, kh, kw, ph, pw,
+    _capi.check(lib.qiddm_qconv_unitary_forward(n_qubits, 0 if reuse else ur.data_ptr(), xx.data_ptr(), b, c, h, w, kh, kw, ph, pw,
                                                 out_channels, int(bool(upsample2x)), bn_ref, int(transposed), y.data_ptr(),
                                                 ws.data_ptr(), ws.numel(), _stream_ptr(device)))
     return y

@@ -170,7 +170,9 @@ int qiddm_qconv_unitary_forward(int32_t n_qubits, const double* u, const double*
   int rc = conv_geometry(n_qubits, batch, in_channels, h_eff, w_eff, kh, kw, pad_h, pad_w, out_channels, &g);
   if (rc != QIDDM_OK) return rc;
   if (batch == 0) return QIDDM_OK;
-  if (!u || !x || !y) return fail(QIDDM_ERR_INVALID, "u/x/y is NULL");
+  // u == NULL: `workspace` still holds the packing of an earlier call for the same unitary and batch norm (an eval-mode
+  // layer whose weights have not changed): the pack launch is skipped
+  if (!x || !y) return fail(QIDDM_ERR_INVALID, "x/y is NULL");
   if (bn && (!bn->running_mean || !bn->running_var || !(bn->eps >= 0.0)))
     return fail(QIDDM_ERR_INVALID, "batch norm needs running_mean / running_var and eps >= 0");
   if (!workspace || workspace_bytes < g.total)
@@ -183,10 +185,11 @@ int qiddm_qconv_unitary_forward(int32_t n_qubits, const double* u, const double*
   double* bnv = reinterpret_cast<double*>(ws + g.off_bn);
   const int d = 1 << n_qubits;
   const int f = (int)(in_channels * kh * kw);
-  hipLaunchKernelGGL(qiddm::qconv_pack_kernel, dim3((unsigned)g.n_pad), dim3(256), 0, st, u, u_transposed ? 1 : 0, d, f,
-                     (int)out_channels, (int)g.k_pad, (int)g.n_pad, g.packed == 3 ? 0 : g.packed, w, padv,
-                     bn ? bn->weight : nullptr, bn ? bn->bias : nullptr, bn ? bn->running_mean : nullptr,
-                     bn ? bn->running_var : nullptr, bn ? bn->eps : 0.0, bnv, (int)(g.n_pad / 2));
+  if (u)
+    hipLaunchKernelGGL(qiddm::qconv_pack_kernel, dim3((unsigned)g.n_pad), dim3(256), 0, st, u, u_transposed ? 1 : 0, d, f,
+                       (int)out_channels, (int)g.k_pad, (int)g.n_pad, g.packed == 3 ? 0 : g.packed, w, padv,
+                       bn ? bn->weight : nullptr, bn ? bn->bias : nullptr, bn ? bn->running_mean : nullptr,
+                       bn ? bn->running_var : nullptr, bn ? bn->eps : 0.0, bnv, (int)(g.n_pad / 2));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(QIDDM_ERR_LAUNCH, "qconv_pack_kernel launch failed: %s", hipGetErrorString(e));
   qiddm::GemmConv gc{};

@@ -67,13 +67,13 @@ class QConv2d(torch.nn.Module):
                 and x.is_cuda and _c._default_precision == "f32" and 2 * self.out_channels <= 2 ** self.wires):
             # eval mode (reference :92-126), up to C4's 12 wires: the cached circuit unitary, then one GEMM
             return _c.qconv_unitary_forward(x, self._eval_unitary(), self.wires, self.out_channels,
-                                            self.kernel_size, self.padding)
+                                            self.kernel_size, self.padding, **self._packed_args())
         if (not torch.is_grad_enabled() and self.qnode is self._own_qnode and self.wires <= 10
                 and 2 * self.out_channels <= 2 ** self.wires):
             if not self.training and x.is_cuda and _c._default_precision == "f32":
                 # eval mode (reference :92-126): the cached circuit unitary, then one GEMM on the matrix cores
                 return _c.qconv_unitary_forward(x, self._eval_unitary(), self.wires, self.out_channels,
-                                                self.kernel_size, self.padding)
+                                                self.kernel_size, self.padding, **self._packed_args())
             # inference: unfold + embedding + circuit + post-processing in one launch
             return _c.qconv_forward(x, _qw_tanh(self.weights.detach().double()), self.wires,
                                     self.out_channels, self.kernel_size, self.padding)
@@ -123,7 +123,14 @@ class QConv2d(torch.nn.Module):
                                        or batch_norm.num_features != self.out_channels):
             return None
         return _c.qconv_unitary_forward(x, self._eval_unitary(), self.wires, self.out_channels, self.kernel_size,
-                                        self.padding, upsample2x=upsample2x, batch_norm=batch_norm)
+                                        self.padding, upsample2x=upsample2x, batch_norm=batch_norm, **self._packed_args())
+
+    def _packed_args(self):
+        """The layer's own packed-operand cache for ``circuit.qconv_unitary_forward`` (valid while ``_sample_stamp``, the
+        stamp of the weights the cached unitary was built from, stands): call AFTER ``_eval_unitary()``."""
+        if not hasattr(self, "_packed_operand"):
+            self._packed_operand = {}
+        return {"packed": self._packed_operand, "packed_key": getattr(self, "_sample_stamp", None)}
 
     def _eval_unitary(self):
         """``sample_matrix`` of the reference (:96-103): the (D, D) complex128 matrix of

@@ -210,3 +210,41 @@ def test_wide_unitary_and_twelve_qubit_eval_convolution():
     tol = 2e-5 * (2 ** 12 / 2) / 8
     assert (y.cpu() - ref).abs().max().item() < tol
     assert (y_sim.cpu() - ref).abs().max().item() < tol
+
+
+def test_packed_operand_is_kept_per_layer_and_follows_weights_and_batchnorm(monkeypatch):
+    """Eval-mode layers pack the GEMM operand once per (weights, BatchNorm) state: the second call hands the library
+    u = NULL (no pack launch) and returns the same numbers; an in-place change of the weights or of the BatchNorm's running
+    statistics packs again."""
+    from qiddm_amd import _capi, nn
+    torch.manual_seed(1)
+    layer = nn.QConv2d(8, 8, 3, 1, 2).to(DEV).eval()
+    bn = torch.nn.BatchNorm2d(8).to(DEV, torch.double).eval()
+    with torch.no_grad():
+        bn.running_mean.uniform_(0.1, 0.3)
+        bn.running_var.uniform_(0.5, 1.5)
+    x = torch.rand(3, 8, 14, 14, dtype=torch.float64, device=DEV)
+    lib = _capi.lib()
+    real = lib.qiddm_qconv_unitary_forward
+    packs = []
+
+    class Spy:
+        def __call__(self, n_qubits, u_ptr, *rest):
+            packs.append(u_ptr != 0)
+            return real(n_qubits, u_ptr, *rest)
+    monkeypatch.setattr(lib, "qiddm_qconv_unitary_forward", Spy())
+    with torch.no_grad():
+        y0 = layer.eval_forward(x, batch_norm=bn)
+        y1 = layer.eval_forward(x, batch_norm=bn)
+        assert packs == [True, False] and torch.equal(y0, y1)
+        bn.running_mean.add_(0.05)                         # the folded BatchNorm is part of the packing
+        y2 = layer.eval_forward(x, batch_norm=bn)
+        assert packs[-1] is True and not torch.equal(y2, y1)
+        ref = torch.nn.functional.batch_norm(layer(x), bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, bn.eps)
+        assert torch.allclose(y2, ref, atol=1e-9)
+        layer.weights.mul_(1.1)
+        n = len(packs)
+        y3 = layer.eval_forward(x, batch_norm=bn)
+        assert packs[n] is True and not torch.allclose(y3, y2)
+        y4 = layer.eval_forward(x, batch_norm=bn)
+        assert packs[-1] is False and torch.equal(y3, y4)
